@@ -1,0 +1,105 @@
+"""Seeded synthetic weights, feature blocks and video sets.
+
+No trained checkpoint or feature file ships with the reference (Google-Drive links,
+/root/reference/README.md:63-64,99-100), so every config of BASELINE.json is exercised on
+synthetic data of the reference's shapes.  numpy `Generator` streams are stable across
+numpy versions, so the same (seed, index) pairs regenerate identical tensors in the
+build container and on the GPU box; that is what lets `tests/golden/*.npz` hold only the
+reference's *outputs*.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+MODALITIES = ("image", "event")
+
+# class keys of the reference's per-class tables (/root/reference/test.py:20-43)
+UCF_CLASSES = ['Abuse', 'Arrest', 'Arson', 'Assault', 'Burglary', 'Explosion', 'Fighting', 'RoadAccidents',
+               'Robbery', 'Shooting', 'Shoplifting', 'Stealing', 'Vandalism', 'Normal']
+
+
+def state_dict_keys(num_layers: int = 2, num_steps: int = 10) -> List[Tuple[str, Tuple[str, ...], str]]:
+    """(key, shape template, kind) for every tensor of the reference's `state_dict`, in its
+    registration order (/root/reference/model/imf_vad.py:69-107)."""
+    out = []
+    for m in MODALITIES:
+        for l in range(num_layers):
+            p = f"temporal.{m}_attn_layers.{l}."
+            out += [(p + "in_proj_weight", ("3D", "D"), "mat"), (p + "in_proj_bias", ("3D",), "bias"),
+                    (p + "out_proj.weight", ("D", "D"), "mat"), (p + "out_proj.bias", ("D",), "bias")]
+        for l in range(num_layers):
+            p = f"temporal.{m}_norms.{l}."
+            out += [(p + "weight", ("D",), "gamma"), (p + "bias", ("D",), "bias")]
+    for m in MODALITIES:
+        out += [(f"temporal.whiten_{m}.weight", ("D",), "gamma"), (f"temporal.whiten_{m}.bias", ("D",), "bias")]
+    for head in ("image_mu", "event_mu", "image_logvar", "event_logvar"):
+        out += [(f"temporal.{head}.weight", ("D", "D"), "mat"), (f"temporal.{head}.bias", ("D",), "bias")]
+    for k in range(num_steps):
+        for j in (0, 2):
+            p = f"temporal.refinement_blocks.{k}.{j}."
+            out += [(p + "weight", ("D", "D"), "mat"), (p + "bias", ("D",), "bias")]
+    out += [("temporal.classifier.weight", ("1", "D"), "mat"), ("temporal.classifier.bias", ("1",), "bias")]
+    return out
+
+
+def make_state_dict(seed: int, D: int = 768, num_layers: int = 2, num_steps: int = 10,
+                    mat_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Seeded weights under the reference's key names and shapes.  Biases and LayerNorm affine
+    terms are deliberately non-trivial (torch's default init has zero attention biases and unit
+    LayerNorm weights, which would hide indexing mistakes)."""
+    sd = {}
+    a = mat_scale / math.sqrt(D)
+    for idx, (key, shape_t, kind) in enumerate(state_dict_keys(num_layers, num_steps)):
+        shape = tuple({"D": D, "3D": 3 * D, "1": 1}[s] for s in shape_t)
+        rng = np.random.default_rng([seed, idx])
+        if kind == "mat":
+            w = rng.uniform(-a, a, size=shape)
+        elif kind == "gamma":
+            w = 1.0 + rng.uniform(-0.1, 0.1, size=shape)
+        else:
+            w = rng.uniform(-0.05, 0.05, size=shape)
+        sd[key] = torch.from_numpy(w.astype(np.float32))
+    return sd
+
+
+def make_inputs(seed: int, B: int, T: int = 256, D: int = 768, scale: float = 0.45,
+                dtype=np.float32) -> Tuple[np.ndarray, np.ndarray]:
+    """Seeded N(0, scale^2) image / event feature blocks [B,T,D] (scale ~ CLIP ViT-L/14 per-dim)."""
+    rng = np.random.default_rng([seed, 1000003])
+    img = (rng.standard_normal((B, T, D)) * scale).astype(dtype)
+    ev = (rng.standard_normal((B, T, D)) * scale).astype(dtype)
+    return img, ev
+
+
+def make_video(seed: int, index: int, length: int, D: int = 768, scale: float = 0.45,
+               dtype=np.float32) -> Tuple[np.ndarray, np.ndarray]:
+    """One synthetic video: image and event feature files of `length` snippets, [length, D]."""
+    rng = np.random.default_rng([seed, 7, index])
+    img = (rng.standard_normal((length, D)) * scale).astype(dtype)
+    ev = (rng.standard_normal((length, D)) * scale).astype(dtype)
+    return img, ev
+
+
+# config 1: at least one video per UCF class key, lengths around the 256 chunk edge
+CONFIG1_LENGTHS = [37, 100, 255, 256, 257, 300, 512, 700, 64, 129, 16, 511, 260, 1, 1500, 90]
+CONFIG1_CLASSES = UCF_CLASSES + ['Normal', 'Arson']
+
+
+def make_gt(seed: int, total_snippets: int, p: float = 0.2) -> np.ndarray:
+    """Frame-level Bernoulli(p) ground truth, 16 frames per snippet, float64 like the
+    reference's gt.npy (/root/reference/test.py:379,129)."""
+    rng = np.random.default_rng([seed, 99])
+    return (rng.random(16 * total_snippets) < p).astype(np.float64)
+
+
+def lognormal_lengths(seed: int, n_videos: int, total: int, lo: int = 16, hi: int = 8000) -> np.ndarray:
+    """Heavy-tailed video lengths rescaled so that they sum to ~`total` snippets (configs 2, 3, 5)."""
+    rng = np.random.default_rng([seed, 5])
+    x = np.exp(rng.normal(0.0, 1.0, n_videos))
+    x = np.clip(x / x.sum() * total, lo, hi)
+    x = np.clip(np.round(x / x.sum() * total), lo, hi).astype(np.int64)
+    return x

@@ -1,0 +1,154 @@
+/*
+ * iefvad.h -- C ABI of libiefvad.so: the MI355X (gfx950) implementation of IEF-VAD's
+ * uncertainty-weighted image-event fusion inference forward.
+ *
+ * The reference has NO native/FFI/plugin boundary for this path: the boundary is a Python
+ * nn.Module call, `outputs = model(img, ev, padding_mask, text, lengths)`
+ * (/root/reference/test.py:111-117, train/ucf_test.py:104-110, train/xd_test.py:98-104,
+ * test2.py:62,79), implemented by `MMFMIL.forward` -> `MultiModal_Fusion_Attn_Iter.forward`
+ * (/root/reference/model/imf_vad.py:40-44, :109-161).  The entry points below are what a
+ * Python `MMFMIL` shim binds with ctypes to replace that forward; INTEGRATION.md shows the
+ * binding.  Plain C types only: pointers are DEVICE pointers (HIP), sizes are in elements
+ * or bytes as stated, the stream is a `hipStream_t` passed as `void*`.
+ *
+ * Ownership: the caller allocates and owns every input, output and workspace buffer.  The
+ * library owns the handle and its repacked copies of the weights.
+ * Errors: every int-returning function returns 0 on success, non-zero on failure, and never
+ * throws or aborts across the ABI; `iefvad_last_error()` returns a thread-local message.
+ * Threading: a handle is bound to the device current at `iefvad_create` and is not
+ * re-entrant; kernels are enqueued on the caller's stream and the call returns without
+ * synchronising.
+ */
+#ifndef IEFVAD_H
+#define IEFVAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IEFVAD_ABI_VERSION 1
+#define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
+#define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
+
+/* noise_model of MultiModal_Fusion_Attn_Iter (/root/reference/model/imf_vad.py:130-138) */
+enum { IEFVAD_NOISE_GAUSSIAN = 0, IEFVAD_NOISE_STUDENT_T = 1 };
+/* element type of the img / ev feature blocks handed to iefvad_forward (the reference casts
+ * whatever arrives with `.to(torch.float)`, imf_vad.py:41-42) */
+enum { IEFVAD_IN_F32 = 0, IEFVAD_IN_F16 = 1, IEFVAD_IN_BF16 = 2 };
+/* arithmetic of the dense projections: F32 = exact-fp32 MFMA (parity mode);
+ * BF16 = bf16 MFMA operands, fp32 accumulation and fp32 fusion state (throughput mode) */
+enum { IEFVAD_COMPUTE_F32 = 0, IEFVAD_COMPUTE_BF16 = 1 };
+
+typedef struct iefvad_handle iefvad_handle;
+
+/* Replaces the constructor arguments that reach the computation:
+ * MMFMIL.__init__ -> MultiModal_Fusion_Attn_Iter(embed_dim, num_layers, num_heads,
+ * num_refinement_steps, lambda_ref, noise_model, nu) (/root/reference/model/imf_vad.py:30-38),
+ * plus epsilon (always 1e-8 in the reference, :58) and visual_length T. */
+typedef struct iefvad_config {
+    int32_t abi_version;   /* IEFVAD_ABI_VERSION */
+    int32_t embed_dim;     /* D, must be 768 */
+    int32_t seq_len;       /* T, must be 256 */
+    int32_t num_heads;     /* H, must be 8 (head dim 96) */
+    int32_t num_layers;    /* L, 1..IEFVAD_MAX_LAYERS */
+    int32_t num_steps;     /* K, 0..IEFVAD_MAX_STEPS */
+    int32_t noise_model;   /* IEFVAD_NOISE_* */
+    int32_t compute;       /* IEFVAD_COMPUTE_* */
+    float lambda_ref;
+    float nu;
+    float epsilon;
+    int32_t micro_batch;   /* chunks processed per internal pass; 0 = library default */
+} iefvad_config;
+
+/* Device pointers to the reference's state_dict tensors, fp32, laid out
+ * as torch stores them: Linear.weight is [out, in] row-major.  Index 0 = image, 1 = event.
+ * Replaces `model.load_state_dict(...)` (/root/reference/test.py:377-378). */
+typedef struct iefvad_weights {
+    const float* in_proj_w[2][IEFVAD_MAX_LAYERS];   /* {m}_attn_layers.l.in_proj_weight [3D, D] */
+    const float* in_proj_b[2][IEFVAD_MAX_LAYERS];   /* ....in_proj_bias   [3D] */
+    const float* out_proj_w[2][IEFVAD_MAX_LAYERS];  /* ....out_proj.weight [D, D] */
+    const float* out_proj_b[2][IEFVAD_MAX_LAYERS];  /* ....out_proj.bias   [D] */
+    const float* norm_w[2][IEFVAD_MAX_LAYERS];      /* {m}_norms.l.weight [D] */
+    const float* norm_b[2][IEFVAD_MAX_LAYERS];      /* {m}_norms.l.bias   [D] */
+    const float* whiten_w[2];                       /* whiten_{m}.weight [D] */
+    const float* whiten_b[2];                       /* whiten_{m}.bias   [D] */
+    const float* mu_w[2];                           /* {m}_mu.weight [D, D] */
+    const float* mu_b[2];                           /* {m}_mu.bias   [D] */
+    const float* logvar_w[2];                       /* {m}_logvar.weight [D, D] */
+    const float* logvar_b[2];                       /* {m}_logvar.bias   [D] */
+    const float* ref_w1[IEFVAD_MAX_STEPS];          /* refinement_blocks.k.0.weight [D, D] */
+    const float* ref_b1[IEFVAD_MAX_STEPS];          /* refinement_blocks.k.0.bias   [D] */
+    const float* ref_w2[IEFVAD_MAX_STEPS];          /* refinement_blocks.k.2.weight [D, D] */
+    const float* ref_b2[IEFVAD_MAX_STEPS];          /* refinement_blocks.k.2.bias   [D] */
+    const float* cls_w;                             /* classifier.weight [1, D] */
+    const float* cls_b;                             /* classifier.bias   [1] */
+} iefvad_weights;
+
+/* Device output buffers; every pointer is optional (NULL = not materialised).  The eight
+ * dict entries of the reference's return value (/root/reference/model/imf_vad.py:152-161),
+ * all fp32, row-major [B*T, D] (logits: [B*T]), plus the per-row means over D of w_i / w_e
+ * that the harness derives on the host (/root/reference/test.py:131-136). */
+typedef struct iefvad_outputs {
+    float* fused;         /* [B*T, D] */
+    float* logits;        /* [B*T]    */
+    float* image_mu;      /* [B*T, D] */
+    float* event_mu;      /* [B*T, D] */
+    float* image_logvar;  /* [B*T, D] */
+    float* event_logvar;  /* [B*T, D] */
+    float* w_i;           /* [B*T, D]  normalised image weight */
+    float* w_e;           /* [B*T, D]  normalised event weight */
+    float* w_i_mean;      /* [B*T]     mean over D of w_i */
+    float* w_e_mean;      /* [B*T]     mean over D of w_e */
+} iefvad_outputs;
+
+/* Per-stage device time of the last iefvad_forward_timed call, milliseconds (hipEvents on the
+ * caller's stream).  Measurement aid for bench.py's roofline block. */
+typedef struct iefvad_stage_times {
+    float total_ms;
+    float qkv_gemm_ms;
+    float attention_ms;
+    float out_gemm_ms;
+    float layernorm_ms;
+    float head_gemm_ms;
+    float fusion_ms;
+    float refine_gemm_ms;
+    float scorer_ms;
+    int32_t gemm_launches;   /* number of dense-projection GEMM launches in the pass */
+} iefvad_stage_times;
+
+int iefvad_abi_version(void);
+
+/* Build a handle on the current HIP device.  Unsupported dimensions or noise_model -> error. */
+int iefvad_create(const iefvad_config* cfg, iefvad_handle** out);
+
+/* Copy/repack the weights into library-owned device memory (stream-ordered on `stream`). */
+int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, void* stream);
+
+/* Bytes of caller-provided scratch that iefvad_forward needs for a call with B chunks. */
+size_t iefvad_workspace_bytes(const iefvad_handle* h, int32_t B);
+
+/* The forward: img, ev are device pointers to [B, T, D] blocks of `in_dtype`, contiguous.
+ * Enqueues on `stream` (hipStream_t) and returns without synchronising. */
+int iefvad_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
+                   void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream);
+
+/* Same forward, bracketing each stage with hipEvents; synchronises the stream before returning. */
+int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
+                         void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream,
+                         iefvad_stage_times* times);
+
+/* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
+ * kernel (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 32 == 0. */
+int iefvad_gemm_bias(const float* A, const float* W, const float* bias, float* C,
+                     int32_t M, int32_t N, int32_t K, int32_t compute, void* stream);
+
+const char* iefvad_last_error(void);
+void iefvad_destroy(iefvad_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IEFVAD_H */

@@ -1,0 +1,174 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run once in the build container (where /root/reference is mounted):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports `model.imf_vad.MMFMIL` and (for the harness fixture) `test.test` from
+/root/reference, loads seeded weights produced by `iefvad_amd.synth.make_state_dict`
+into the reference model with `load_state_dict`, runs seeded inputs through it and stores the
+reference's OUTPUTS only.  Weights and inputs are regenerated from their seeds by the tests,
+so the committed files stay small and contain no reference source.
+
+The reference never travels to the GPU box; these .npz files and this script do.
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from iefvad_amd import synth  # noqa: E402
+
+ROW_SUBSET = [0, 1, 37, 99, 100, 101, 128, 200, 254, 255]   # rows of each chunk kept for the 768-d outputs
+BIG_KEYS = ["fused", "image_mu", "event_mu", "image_logvar", "event_logvar", "w_i", "w_e"]
+
+
+def ref_args(L=2, H=8, K=10, lam=0.5, noise="StudentT", nu=8):
+    return argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K, lambda_ref=lam,
+                              noise_model=noise, nu=nu)
+
+
+def build_reference(seed, L=2, K=10, lam=0.5, noise="StudentT", nu=8):
+    sys.path.insert(0, REF)
+    from model.imf_vad import MMFMIL  # the reference model
+    model = MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, device="cpu", args=ref_args(L, 8, K, lam, noise, nu))
+    sd = synth.make_state_dict(seed, 768, L, K)
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    return model
+
+
+# (name, weight seed, input seed, B, L, K, lambda, noise, nu, input dtype, input edit)
+CASES = [
+    ("base_k10_student8", 11, 21, 3, 2, 10, 0.5, "StudentT", 8, "f32", "tail"),      # chunk 2 zero-padded after row 100
+    ("allzero_chunk", 11, 22, 2, 2, 10, 0.5, "StudentT", 8, "f32", "allzero"),       # chunk 1 entirely zero
+    ("fp16_in", 11, 23, 1, 2, 10, 0.5, "StudentT", 8, "f16", None),
+    ("k0_gauss", 12, 24, 1, 2, 0, 0.5, "Gaussian", 5, "f32", None),
+    ("k3_student5", 13, 25, 1, 2, 3, 0.5, "StudentT", 5, "f32", None),
+    ("k5_gauss_lam03", 14, 26, 2, 2, 5, 0.3, "Gaussian", 8, "f32", "tail"),
+    ("l1_k2", 15, 27, 1, 1, 2, 0.5, "StudentT", 8, "f32", None),
+    ("l3_k1", 16, 28, 1, 3, 1, 0.5, "StudentT", 8, "f32", None),
+]
+
+
+def case_inputs(in_seed, B, dtype, edit):
+    img, ev = synth.make_inputs(in_seed, B)
+    if edit == "tail":
+        img[B - 1, 100:] = 0
+        ev[B - 1, 100:] = 0
+    elif edit == "allzero":
+        img[B - 1] = 0
+        ev[B - 1] = 0
+    if dtype == "f16":
+        img, ev = img.astype(np.float16), ev.astype(np.float16)
+    return img, ev
+
+
+def gen_forward_cases():
+    for name, wseed, iseed, B, L, K, lam, noise, nu, dt, edit in CASES:
+        model = build_reference(wseed, L, K, lam, noise, nu)
+        img, ev = case_inputs(iseed, B, dt, edit)
+        with torch.no_grad():
+            out = model(torch.from_numpy(img), torch.from_numpy(ev), None, None, None)
+        store = {"logits": out["logits"].numpy().reshape(B, 256),
+                 "w_i_mean": out["w_i"].mean(dim=-1).numpy(), "w_e_mean": out["w_e"].mean(dim=-1).numpy(),
+                 "rows": np.array(ROW_SUBSET),
+                 "meta": np.array([wseed, iseed, B, L, K, nu]), "lam": np.array(lam),
+                 "noise": np.array(noise), "in_dtype": np.array(dt), "edit": np.array(str(edit))}
+        for k in BIG_KEYS:
+            store[k] = out[k].numpy()[:, ROW_SUBSET, :]
+        path = os.path.join(HERE, f"fwd_{name}.npz")
+        np.savez_compressed(path, **store)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_harness_case():
+    """Config 1: a synthetic UCF-shaped .npy set through the reference's own
+    `test.test()` loop (/root/reference/test.py:46-212)."""
+    sys.path.insert(0, REF)
+    seed = 0
+    lengths, classes = synth.CONFIG1_LENGTHS, synth.CONFIG1_CLASSES
+    tmp = tempfile.mkdtemp(prefix="iefvad_cfg1_")
+    rows = []
+    for i, (n, c) in enumerate(zip(lengths, classes)):
+        img, ev = synth.make_video(seed, i, n)
+        if i == 2:            # one NaN element exercises the conditional nan_to_num (test.py:90-95)
+            img[5, 7] = np.nan
+        if i == 5:            # one fp16 file: dtype is preserved by the loader (dataset.py:49-50)
+            img, ev = img.astype(np.float16), ev.astype(np.float16)
+        d_rgb = os.path.join(tmp, "feat", "rgb", c)
+        d_ev = os.path.join(tmp, "feat", "event_thr_10", c)
+        os.makedirs(d_rgb, exist_ok=True)
+        os.makedirs(d_ev, exist_ok=True)
+        p = os.path.join(d_rgb, f"v{i:03d}__5.npy")
+        np.save(p, img)
+        np.save(p.replace("rgb", "event_thr_10"), ev)
+        rows.append((p, c))
+    csv = os.path.join(tmp, "test.csv")
+    with open(csv, "w") as f:
+        f.write("path,label\n")
+        for p, c in rows:
+            f.write(f"{p},{c}\n")
+    gt = synth.make_gt(seed, int(sum(lengths)))
+
+    cwd = os.getcwd()
+    os.chdir(tmp)     # test() does os.makedirs('vis') (test.py:59-62)
+    try:
+        import test as ref_test                      # /root/reference/test.py
+        from data.dataset import UCF_Dataset         # /root/reference/data/dataset.py
+        from torch.utils.data import DataLoader
+        model = build_reference(11)
+        captured = {"logits": [], "ano": None}
+
+        class Recorder(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, *a, **k):
+                o = self.inner(*a, **k)
+                captured["logits"].append(o["logits"].detach().clone())
+                return o
+
+        orig_ano = ref_test.compute_ano_auc
+
+        def ano_wrap(*a, **k):
+            captured["ano"] = orig_ano(*a, **k)
+            return captured["ano"]
+
+        ref_test.compute_ano_auc = ano_wrap
+        loader = DataLoader(UCF_Dataset(256, csv, True, None), batch_size=1, shuffle=False)
+        args = argparse.Namespace(exp_name="golden", dataset="ucfcrime")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            roc, ap = ref_test.test(args, Recorder(model), loader, 256, None, gt, "cpu", attn=False, vis=False)
+        print(buf.getvalue())
+    finally:
+        os.chdir(cwd)
+    probs = []
+    for lg, n in zip(captured["logits"], lengths):
+        probs.append(torch.sigmoid(lg.reshape(-1)[:n]).numpy())
+    path = os.path.join(HERE, "harness_config1.npz")
+    np.savez_compressed(path, scores=np.concatenate(probs), lengths=np.array(lengths),
+                        classes=np.array(classes), roc=np.array(roc), ap=np.array(ap),
+                        ano_auc=np.array(captured["ano"]), seed=np.array(seed), wseed=np.array(11),
+                        chunks=np.array([lg.shape[0] for lg in captured["logits"]]),
+                        stdout=np.array(buf.getvalue()))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "ROC", roc, "AP", ap, "ano", captured["ano"])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    gen_forward_cases()
+    gen_harness_case()

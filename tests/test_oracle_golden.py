@@ -1,0 +1,75 @@
+"""The CPU oracle (oracle/iefvad_oracle.py) against the golden vectors captured from the
+reference model itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("name", H.golden_cases())
+def test_oracle_matches_reference_outputs(name):
+    g, cfg, sd, img, ev = H.load_case(name)
+    out = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), H.oracle_cfg(cfg))
+    out = {k: v.numpy() for k, v in out.items()}
+    errs = H.compare_outputs(out, g)
+    # per-row means that the harness derives (test.py:131-136)
+    assert np.abs(out["w_i"].mean(-1) - g["w_i_mean"]).max() < 2e-6
+    assert np.abs(out["w_e"].mean(-1) - g["w_e_mean"]).max() < 2e-6
+    print(name, errs)
+
+
+def test_oracle_fp64_noise_floor():
+    """fp32 vs fp64 evaluation of the same restatement: the noise floor the fp32 gates sit on."""
+    g, cfg, sd, img, ev = H.load_case("base_k10_student8")
+    o32 = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), H.oracle_cfg(cfg), torch.float32)
+    o64 = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), H.oracle_cfg(cfg), torch.float64)
+    for k in o32:
+        d = (o32[k].double() - o64[k]).abs().max().item()
+        assert d < 1e-5, (k, d)
+
+
+def test_oracle_rejects_unknown_noise_model():
+    g, cfg, sd, img, ev = H.load_case("l1_k2")
+    c = H.oracle_cfg(cfg)
+    c.noise_model = "Laplace"
+    with pytest.raises(ValueError):   # reference: imf_vad.py:137-138
+        orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), c)
+
+
+def test_process_split_shapes():
+    """Chunk rule of data/tools.py:100-114 (shapes probed on the reference)."""
+    for n, shape in [(100, (256, 768)), (37, (256, 768)), (256, (2, 256, 768)), (300, (2, 256, 768)),
+                     (512, (3, 256, 768)), (700, (3, 256, 768))]:
+        f = np.ones((n, 768), np.float32)
+        out, ln = orc.process_split(f, 256)
+        assert out.shape == shape and ln == n
+        assert out.reshape(-1, 768)[:n].min() == 1 and out.reshape(-1, 768)[n:].max(initial=0) == 0
+
+
+def test_oracle_harness_scores_match_reference_test_loop(golden_dir):
+    """Per-video sigmoid scores of config 1 vs the scores captured inside the reference's test()."""
+    import os
+    from iefvad_amd import synth
+    g = np.load(os.path.join(golden_dir, "harness_config1.npz"))
+    lengths = [int(v) for v in g["lengths"]]
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(int(g["wseed"]))
+    model = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    # the 4 shortest and 2 multi-chunk videos keep the CPU suite fast; the full set runs in test_harness
+    pick = [0, 1, 3, 5, 13]
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    vids = []
+    for i in pick:
+        img, ev = synth.make_video(seed, i, lengths[i])
+        if i == 2:
+            img[5, 7] = np.nan
+        if i == 5:
+            img, ev = img.astype(np.float16), ev.astype(np.float16)
+        vids.append((img, ev))
+    scores = orc.score_videos(model, vids)
+    for i, s in zip(pick, scores):
+        ref = g["scores"][offs[i]:offs[i + 1]]
+        assert s.shape == ref.shape
+        assert np.abs(s - ref).max() < 2e-6
