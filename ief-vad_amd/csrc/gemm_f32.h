@@ -1,0 +1,183 @@
+// Dense projection GEMM for the d=768 layers, exact fp32 on the CDNA4 matrix cores.
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] )
+//
+// Every Linear / in_proj / out_proj of the reference forward
+// (/root/reference/model/imf_vad.py:115,121,125-128,148,150) is this contraction with
+// K = 768 and W stored [out,in] exactly as torch stores nn.Linear.weight, so both operands
+// are K-contiguous ("NT").
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves in a 2x2 grid, each wave a 64x64
+// sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs).  One MFMA takes lane (i, h):
+// A[i][k=h], B[k=h][j=i'].  A lane fetches its operands as one ds_read_b128 = 4 consecutive k of
+// its row and feeds them to 4 consecutive MFMAs; lane half h takes k = 8s+4h .. 8s+4h+3 of each
+// 8-wide k group, so each half sums a different (but complete and disjoint) set of k: the order of
+// the K summation differs from a sequential loop, the set of products does not.
+// LDS image: [row][32 floats] with the 16-byte chunk index XORed by (row>>1)&7, which makes the
+// four 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (conflict-free).
+// Staging is register based (global_load_dwordx4 -> ds_write_b128), issued one k-tile ahead so the
+// loads fly under the 64 MFMAs of the current tile; LDS is double buffered, one barrier per tile.
+// 64 KB LDS + <=128 VGPRs -> 2 blocks per CU, so one block's barrier wait hides under the other's MFMAs.
+#pragma once
+#include "common.h"
+
+enum GemmEpilogue {
+    EPI_BIAS = 0,        // C = acc + bias
+    EPI_QKV = 1,         // C = (acc + bias) * (n < qcols ? qscale : 1)      in_proj; q pre-scaled by 1/sqrt(dh)
+    EPI_BIAS_RELU = 2,   // C = relu(acc + bias)                              refinement Linear -> ReLU
+    EPI_BIAS_RESID = 3,  // C = acc + bias + R                                out_proj + residual (x + attn_out)
+    EPI_REFINE = 4,      // C = R - alpha * (acc + bias)                      z - lambda * block(z)
+    EPI_HEADS = 5,       // n < 768: C = acc + bias ; n >= 768: C2 = acc + bias   (mu | logvar heads share A)
+};
+
+struct GemmProblem {
+    const float* A;      // [M, K], row stride lda
+    const float* W;      // [N, K], row stride K (dense)
+    const float* bias;   // [N]
+    float* C;            // [M, ldc]
+    const float* R;      // residual input, [M, ldc] (same layout as C); may alias C
+    float* C2;           // second output for EPI_HEADS, [M, 768]
+};
+
+struct GemmArgs {
+    GemmProblem p[2];    // blockIdx.z selects (image / event share shapes, differ in weights)
+    int M, N, K;
+    int lda, ldc;
+    int epi;
+    float alpha;         // lambda (EPI_REFINE) or qscale (EPI_QKV)
+    int qcols;           // EPI_QKV: columns < qcols are scaled
+};
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 32
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GEMM_BM + GEMM_BN) * GEMM_BK];   // 64 KB
+    const GemmProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GEMM_BN;
+    const int nwg = gridDim.x;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int K = args.K, lda = args.lda;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+
+    // staging: thread t moves chunk (row = (t>>3) + 32 j, ch = t&7), j = 0..3, of both tiles
+    const int srow = t >> 3, sch = t & 7;
+    const float* gA = P.A + (size_t)(m0 + srow) * lda + sch * 4;
+    const float* gW = P.W + (size_t)(n0 + srow) * K + sch * 4;
+    const int sdst = srow * GEMM_BK + ((sch ^ ((srow >> 1) & 7)) << 2);   // (row>>1)&7 is j-invariant
+
+    // fragment read offsets (floats) inside a tile image
+    const int fsw = (i >> 1) & 7;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        aoff[x] = (wr * 64 + x * 32 + i) * GEMM_BK;
+        boff[x] = (wc * 64 + x * 32 + i) * GEMM_BK;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ra[4], rw[4];
+    const int nk = K / GEMM_BK;
+    // prologue: tile 0 -> LDS buffer 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ra[j] = *(const f32x4*)(gA + (size_t)(32 * j) * lda);
+        rw[j] = *(const f32x4*)(gW + (size_t)(32 * j) * K);
+    }
+    {
+        float* As = smem;
+        float* Ws = smem + 2 * GEMM_BM * GEMM_BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(As + sdst + 32 * j * GEMM_BK) = ra[j];
+            *(f32x4*)(Ws + sdst + 32 * j * GEMM_BK) = rw[j];
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int k1 = (kt + 1) * GEMM_BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *(const f32x4*)(gA + (size_t)(32 * j) * lda + k1);
+                rw[j] = *(const f32x4*)(gW + (size_t)(32 * j) * K + k1);
+            }
+        }
+        const float* As = smem + cur * GEMM_BM * GEMM_BK;
+        const float* Ws = smem + 2 * GEMM_BM * GEMM_BK + cur * GEMM_BN * GEMM_BK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = ((2 * s + h) ^ fsw) << 2;
+            f32x4 fa[2], fb[2];
+            fa[0] = *(const f32x4*)(As + aoff[0] + ch);
+            fa[1] = *(const f32x4*)(As + aoff[1] + ch);
+            fb[0] = *(const f32x4*)(Ws + boff[0] + ch);
+            fb[1] = *(const f32x4*)(Ws + boff[1] + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[1][e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float* Ad = smem + (cur ^ 1) * GEMM_BM * GEMM_BK;
+            float* Wd = smem + 2 * GEMM_BM * GEMM_BK + (cur ^ 1) * GEMM_BN * GEMM_BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(f32x4*)(Ad + sdst + 32 * j * GEMM_BK) = ra[j];
+                *(f32x4*)(Wd + sdst + 32 * j * GEMM_BK) = rw[j];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int epi = args.epi;
+    const int ldc = args.ldc;
+    const float alpha = args.alpha;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wc * 64 + b * 32 + i;
+        const float bv = P.bias[n];
+        float* Cb = P.C;
+        int nn = n;
+        float scale = 1.f;
+        if (epi == EPI_HEADS && n >= IEF_D) { Cb = P.C2; nn = n - IEF_D; }
+        if (epi == EPI_QKV && n < args.qcols) scale = alpha;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int mb = m0 + wr * 64 + a * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const size_t o = (size_t)m * ldc + nn;
+                float v = acc[a][b][r] + bv;
+                if (epi == EPI_QKV) v *= scale;
+                else if (epi == EPI_BIAS_RELU) v = (v < 0.f) ? 0.f : v;
+                else if (epi == EPI_BIAS_RESID) v = v + P.R[o];
+                else if (epi == EPI_REFINE) v = P.R[o] - alpha * v;
+                Cb[o] = v;
+            }
+        }
+    }
+}

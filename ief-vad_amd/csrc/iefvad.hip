@@ -1,0 +1,454 @@
+// libiefvad.so -- C ABI (include/iefvad.h) and launch orchestration of the IEF-VAD fusion forward
+// on MI355X.  Replaces MMFMIL.forward -> MultiModal_Fusion_Attn_Iter.forward
+// (/root/reference/model/imf_vad.py:40-44, :109-161).  gfx950 only; no host fallback.
+#include "../../include/iefvad.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "attention_f32.h"
+#include "common.h"
+#include "gemm_f32.h"
+#include "rowops.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct iefvad_handle {
+    iefvad_config cfg;
+    int device;
+    bool weights_set;
+    float* arena;          // one allocation holding every repacked weight
+    size_t arena_floats;
+    // pointers into the arena
+    float* in_w[2][IEFVAD_MAX_LAYERS];
+    float* in_b[2][IEFVAD_MAX_LAYERS];
+    float* out_w[2][IEFVAD_MAX_LAYERS];
+    float* out_b[2][IEFVAD_MAX_LAYERS];
+    float* norm_w[2][IEFVAD_MAX_LAYERS];
+    float* norm_b[2][IEFVAD_MAX_LAYERS];
+    float* whiten_w[2];
+    float* whiten_b[2];
+    float* head_w[2];      // [1536, 768] = mu.weight stacked over logvar.weight
+    float* head_b[2];      // [1536]
+    float* ref_w1[IEFVAD_MAX_STEPS];
+    float* ref_b1[IEFVAD_MAX_STEPS];
+    float* ref_w2[IEFVAD_MAX_STEPS];
+    float* ref_b2[IEFVAD_MAX_STEPS];
+    float* cls_w;
+    float* cls_b;
+};
+
+static const int kDefaultMicroBatch = 128;   // chunks per internal pass (32768 rows)
+
+static int micro_batch(const iefvad_handle* h) {
+    return h->cfg.micro_batch > 0 ? h->cfg.micro_batch : kDefaultMicroBatch;
+}
+
+extern "C" int iefvad_abi_version(void) { return IEFVAD_ABI_VERSION; }
+
+extern "C" const char* iefvad_last_error(void) { return g_err; }
+
+extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
+    if (!cfg || !out) return fail("iefvad_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != IEFVAD_ABI_VERSION)
+        return fail("iefvad_create: abi_version %d, library is %d", cfg->abi_version, IEFVAD_ABI_VERSION);
+    if (cfg->embed_dim != IEF_D || cfg->seq_len != IEF_T || cfg->num_heads != IEF_H)
+        return fail("iefvad_create: kernels are built for D=768, T=256, H=8 (got D=%d T=%d H=%d)",
+                    cfg->embed_dim, cfg->seq_len, cfg->num_heads);
+    if (cfg->num_layers < 1 || cfg->num_layers > IEFVAD_MAX_LAYERS)
+        return fail("iefvad_create: num_layers %d outside 1..%d", cfg->num_layers, IEFVAD_MAX_LAYERS);
+    if (cfg->num_steps < 0 || cfg->num_steps > IEFVAD_MAX_STEPS)
+        return fail("iefvad_create: num_steps %d outside 0..%d", cfg->num_steps, IEFVAD_MAX_STEPS);
+    if (cfg->noise_model != IEFVAD_NOISE_GAUSSIAN && cfg->noise_model != IEFVAD_NOISE_STUDENT_T)
+        return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");   // imf_vad.py:138
+    if (cfg->compute != IEFVAD_COMPUTE_F32)
+        return fail("iefvad_create: compute mode %d not built (only IEFVAD_COMPUTE_F32)", cfg->compute);
+    if (cfg->noise_model == IEFVAD_NOISE_STUDENT_T && !(cfg->nu != 0.f))
+        return fail("iefvad_create: nu must be non-zero for StudentT");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("iefvad_create: no HIP device");
+    iefvad_handle* h = new (std::nothrow) iefvad_handle();
+    if (!h) return fail("iefvad_create: out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_f32_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    if (e != hipSuccess) {
+        delete h;
+        return fail("iefvad_create: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void iefvad_destroy(iefvad_handle* h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, void* stream_) {
+    if (!h || !w) return fail("iefvad_set_weights: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = h->cfg.num_layers, K = h->cfg.num_steps;
+    const size_t D = IEF_D, DD = D * D;
+    // validate pointers first
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l < L; ++l)
+            if (!w->in_proj_w[m][l] || !w->in_proj_b[m][l] || !w->out_proj_w[m][l] || !w->out_proj_b[m][l] ||
+                !w->norm_w[m][l] || !w->norm_b[m][l])
+                return fail("iefvad_set_weights: null encoder weight (modality %d layer %d)", m, l);
+        if (!w->whiten_w[m] || !w->whiten_b[m] || !w->mu_w[m] || !w->mu_b[m] || !w->logvar_w[m] || !w->logvar_b[m])
+            return fail("iefvad_set_weights: null head weight (modality %d)", m);
+    }
+    for (int k = 0; k < K; ++k)
+        if (!w->ref_w1[k] || !w->ref_b1[k] || !w->ref_w2[k] || !w->ref_b2[k])
+            return fail("iefvad_set_weights: null refinement weight (step %d)", k);
+    if (!w->cls_w || !w->cls_b) return fail("iefvad_set_weights: null classifier weight");
+
+    const size_t total = 2 * L * (3 * DD + 3 * D + DD + D + 2 * D) + 2 * (2 * D) + 2 * (2 * DD + 2 * D) +
+                         (size_t)K * (2 * DD + 2 * D) + D + 4;
+    if (!h->arena) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMalloc((void**)&h->arena, total * sizeof(float)));
+        h->arena_floats = total;
+    }
+    float* p = h->arena;
+    auto put = [&](float** dst, const float* src, size_t n) -> hipError_t {
+        *dst = p;
+        p += n;
+        return hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    };
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l < L; ++l) {
+            HIP_TRY(put(&h->in_w[m][l], w->in_proj_w[m][l], 3 * DD));
+            HIP_TRY(put(&h->in_b[m][l], w->in_proj_b[m][l], 3 * D));
+            HIP_TRY(put(&h->out_w[m][l], w->out_proj_w[m][l], DD));
+            HIP_TRY(put(&h->out_b[m][l], w->out_proj_b[m][l], D));
+            HIP_TRY(put(&h->norm_w[m][l], w->norm_w[m][l], D));
+            HIP_TRY(put(&h->norm_b[m][l], w->norm_b[m][l], D));
+        }
+        HIP_TRY(put(&h->whiten_w[m], w->whiten_w[m], D));
+        HIP_TRY(put(&h->whiten_b[m], w->whiten_b[m], D));
+        // mu | logvar heads share their A operand: stack them into one [1536, 768] projection
+        HIP_TRY(put(&h->head_w[m], w->mu_w[m], DD));
+        float* dummy;
+        HIP_TRY(put(&dummy, w->logvar_w[m], DD));
+        HIP_TRY(put(&h->head_b[m], w->mu_b[m], D));
+        HIP_TRY(put(&dummy, w->logvar_b[m], D));
+    }
+    for (int k = 0; k < K; ++k) {
+        HIP_TRY(put(&h->ref_w1[k], w->ref_w1[k], DD));
+        HIP_TRY(put(&h->ref_b1[k], w->ref_b1[k], D));
+        HIP_TRY(put(&h->ref_w2[k], w->ref_w2[k], DD));
+        HIP_TRY(put(&h->ref_b2[k], w->ref_b2[k], D));
+    }
+    HIP_TRY(put(&h->cls_w, w->cls_w, D));
+    HIP_TRY(put(&h->cls_b, w->cls_b, 1));
+    if ((size_t)(p - h->arena) > h->arena_floats) return fail("iefvad_set_weights: arena overflow");
+    h->weights_set = true;
+    return 0;
+}
+
+// workspace, in floats per row: xin(2) + qkv(6) + att(2) + y(2) + x(2) = 14 * 768, + 1 (logits scratch).
+// mu_i, lv_i, mu_e, lv_e, z, h alias the qkv region (6 * 768), which is dead once the encoder is done.
+static const size_t kWsFloatsPerRow = 14 * IEF_D + 4;
+
+extern "C" size_t iefvad_workspace_bytes(const iefvad_handle* h, int32_t B) {
+    if (!h || B <= 0) return 0;
+    const int mb = micro_batch(h);
+    const size_t rows = (size_t)(B < mb ? B : mb) * IEF_T;
+    return rows * kWsFloatsPerRow * sizeof(float) + 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage timing
+// ------------------------------------------------------------------------------------------------
+enum Stage { ST_QKV = 0, ST_ATT, ST_OUT, ST_LN, ST_HEAD, ST_FUSION, ST_REFINE, ST_SCORER, ST_CAST, ST_COUNT };
+
+struct Timer {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    struct Span { int stage; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    int gemm_launches = 0;
+    hipEvent_t begin(int stage) {
+        if (!on) return nullptr;
+        Span s;
+        s.stage = stage;
+        (void)hipEventCreate(&s.a);
+        (void)hipEventCreate(&s.b);
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+        return s.b;
+    }
+    void end(hipEvent_t b) {
+        if (on && b) (void)hipEventRecord(b, stream);
+    }
+};
+
+static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
+    if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
+        return fail("gemm: shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
+                    GEMM_BK);
+    dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
+    hipEvent_t e = tm.begin(stage);
+    hipLaunchKernelGGL(iefvad_gemm_f32_kernel, grid, dim3(256), 0, stream, a);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int launch_cast(const void* img, const void* ev, float* o0, float* o1, size_t n, hipStream_t stream) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iefvad_cast_kernel<T>, dim3((unsigned)blocks, 2), dim3(256), 0, stream, (const T*)img,
+                       (const T*)ev, o0, o1, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static size_t in_elem_bytes(int in_dtype) { return in_dtype == IEFVAD_IN_F32 ? 4 : 2; }
+
+static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
+                        size_t workspace_bytes, const iefvad_outputs* out, hipStream_t stream, Timer& tm) {
+    if (!h || !img || !ev || !out) return fail("iefvad_forward: null argument");
+    if (!h->weights_set) return fail("iefvad_forward: weights not set");
+    if (B <= 0) return fail("iefvad_forward: B must be positive (got %d)", B);
+    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
+        return fail("iefvad_forward: unknown in_dtype %d", in_dtype);
+    if (!workspace || workspace_bytes < iefvad_workspace_bytes(h, B))
+        return fail("iefvad_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, iefvad_workspace_bytes(h, B));
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)img & 15) || ((uintptr_t)ev & 15))
+        return fail("iefvad_forward: buffers must be 16-byte aligned");
+
+    const iefvad_config& c = h->cfg;
+    const int L = c.num_layers, K = c.num_steps;
+    const int mb = micro_batch(h);
+    const size_t D = IEF_D;
+    const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;   // imf_vad.py:134
+    const float qscale = 1.0f / sqrtf((float)IEF_DH);
+
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = (B - b0 < mb) ? (B - b0) : mb;
+        const int rows = nb * IEF_T;
+        const size_t R = (size_t)rows;
+        const size_t row0 = (size_t)b0 * IEF_T;
+        float* ws = (float*)workspace;
+        float* xin[2] = {ws, ws + R * D};
+        float* qkv[2] = {ws + 2 * R * D, ws + 5 * R * D};
+        float* att[2] = {ws + 8 * R * D, ws + 9 * R * D};
+        float* ybuf[2] = {ws + 10 * R * D, ws + 11 * R * D};
+        float* xbuf[2] = {ws + 12 * R * D, ws + 13 * R * D};
+        float* lg_scratch = ws + 14 * R * D;
+        // tail buffers alias the (dead by then) qkv region
+        float* t0 = ws + 2 * R * D;
+        float* mu_i = out->image_mu ? out->image_mu + row0 * D : t0;
+        float* lv_i = out->image_logvar ? out->image_logvar + row0 * D : t0 + R * D;
+        float* mu_e = out->event_mu ? out->event_mu + row0 * D : t0 + 2 * R * D;
+        float* lv_e = out->event_logvar ? out->event_logvar + row0 * D : t0 + 3 * R * D;
+        float* z = out->fused ? out->fused + row0 * D : t0 + 4 * R * D;
+        float* hbuf = t0 + 5 * R * D;
+        float* logits = out->logits ? out->logits + row0 : lg_scratch;
+
+        const float* cur[2];
+        const size_t in_off = row0 * D * in_elem_bytes(in_dtype);
+        if (in_dtype == IEFVAD_IN_F32) {
+            cur[0] = (const float*)((const char*)img + in_off);
+            cur[1] = (const float*)((const char*)ev + in_off);
+        } else {
+            hipEvent_t e = tm.begin(ST_CAST);
+            int rc = (in_dtype == IEFVAD_IN_F16)
+                         ? launch_cast<__half>((const char*)img + in_off, (const char*)ev + in_off, xin[0], xin[1], R * D, stream)
+                         : launch_cast<__hip_bfloat16>((const char*)img + in_off, (const char*)ev + in_off, xin[0], xin[1],
+                                                       R * D, stream);
+            tm.end(e);
+            if (rc) return rc;
+            cur[0] = xin[0];
+            cur[1] = xin[1];
+        }
+
+        // 1. temporal encoder (imf_vad.py:113-123): L x { in_proj, attention, out_proj + residual, LayerNorm }
+        for (int l = 0; l < L; ++l) {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.M = rows; g.N = 3 * IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = 3 * IEF_D;
+            g.epi = EPI_QKV; g.alpha = qscale; g.qcols = IEF_D;
+            for (int m = 0; m < 2; ++m) {
+                g.p[m].A = cur[m]; g.p[m].W = h->in_w[m][l]; g.p[m].bias = h->in_b[m][l]; g.p[m].C = qkv[m];
+            }
+            if (int rc = launch_gemm(g, 2, stream, tm, ST_QKV)) return rc;
+
+            AttnArgs aa;
+            for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
+            hipEvent_t e = tm.begin(ST_ATT);
+            hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 2), dim3(512), ATT_LDS_BYTES, stream, aa);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+
+            memset(&g, 0, sizeof(g));
+            g.M = rows; g.N = IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_BIAS_RESID;
+            for (int m = 0; m < 2; ++m) {
+                g.p[m].A = att[m]; g.p[m].W = h->out_w[m][l]; g.p[m].bias = h->out_b[m][l]; g.p[m].C = ybuf[m];
+                g.p[m].R = cur[m];
+            }
+            if (int rc = launch_gemm(g, 2, stream, tm, ST_OUT)) return rc;
+
+            LnArgs la;
+            memset(&la, 0, sizeof(la));
+            la.nrows = rows; la.eps = 1e-5f;
+            for (int m = 0; m < 2; ++m) {
+                la.x[m] = ybuf[m]; la.y[m] = xbuf[m]; la.g1[m] = h->norm_w[m][l]; la.b1[m] = h->norm_b[m][l];
+                if (l == L - 1) { la.g2[m] = h->whiten_w[m]; la.b2[m] = h->whiten_b[m]; }   // whitening LN, :117,:123
+            }
+            e = tm.begin(ST_LN);
+            hipLaunchKernelGGL(iefvad_layernorm_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES, 2), dim3(256), 0, stream, la);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+            cur[0] = xbuf[0];
+            cur[1] = xbuf[1];
+        }
+
+        // 2. mu / logvar heads (imf_vad.py:125-128): one [768 -> 1536] projection per modality
+        {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.M = rows; g.N = 2 * IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_HEADS;
+            g.p[0].A = xbuf[0]; g.p[0].W = h->head_w[0]; g.p[0].bias = h->head_b[0]; g.p[0].C = mu_i; g.p[0].C2 = lv_i;
+            g.p[1].A = xbuf[1]; g.p[1].W = h->head_w[1]; g.p[1].bias = h->head_b[1]; g.p[1].C = mu_e; g.p[1].C2 = lv_e;
+            if (int rc = launch_gemm(g, 2, stream, tm, ST_HEAD)) return rc;
+        }
+
+        // 3. precision weights + fusion (imf_vad.py:130-144)
+        {
+            FusionArgs fa;
+            fa.mu_i = mu_i; fa.lv_i = lv_i; fa.mu_e = mu_e; fa.lv_e = lv_e;
+            fa.n_i = out->w_i ? out->w_i + row0 * D : nullptr;
+            fa.n_e = out->w_e ? out->w_e + row0 * D : nullptr;
+            fa.z = z;
+            fa.n_i_mean = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
+            fa.n_e_mean = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
+            fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
+            hipEvent_t e = tm.begin(ST_FUSION);
+            hipLaunchKernelGGL(iefvad_fusion_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+        }
+
+        // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149)
+        for (int k = 0; k < K; ++k) {
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.M = rows; g.N = IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_BIAS_RELU;
+            g.p[0].A = z; g.p[0].W = h->ref_w1[k]; g.p[0].bias = h->ref_b1[k]; g.p[0].C = hbuf;
+            if (int rc = launch_gemm(g, 1, stream, tm, ST_REFINE)) return rc;
+            g.epi = EPI_REFINE; g.alpha = c.lambda_ref;
+            g.p[0].A = hbuf; g.p[0].W = h->ref_w2[k]; g.p[0].bias = h->ref_b2[k]; g.p[0].C = z; g.p[0].R = z;
+            if (int rc = launch_gemm(g, 1, stream, tm, ST_REFINE)) return rc;
+        }
+
+        // 5. scorer (imf_vad.py:150)
+        {
+            hipEvent_t e = tm.begin(ST_SCORER);
+            hipLaunchKernelGGL(iefvad_scorer_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, z,
+                               h->cls_w, h->cls_b, logits, rows);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+extern "C" int iefvad_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
+                              size_t workspace_bytes, const iefvad_outputs* out, void* stream) {
+    Timer tm;
+    return forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream, tm);
+}
+
+extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
+                                    void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream_,
+                                    iefvad_stage_times* times) {
+    if (!times) return fail("iefvad_forward_timed: null times");
+    hipStream_t stream = (hipStream_t)stream_;
+    Timer tm;
+    tm.on = true;
+    tm.stream = stream;
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, stream));
+    int rc = forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, stream, tm);
+    (void)hipEventRecord(t1, stream);
+    hipError_t se = hipStreamSynchronize(stream);
+    float acc[ST_COUNT] = {0};
+    for (auto& s : tm.spans) {
+        float ms = 0.f;
+        if (se == hipSuccess && rc == 0) (void)hipEventElapsedTime(&ms, s.a, s.b);
+        acc[s.stage] += ms;
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    float total = 0.f;
+    if (se == hipSuccess && rc == 0) (void)hipEventElapsedTime(&total, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (rc) return rc;
+    if (se != hipSuccess) return fail("iefvad_forward_timed: %s", hipGetErrorString(se));
+    memset(times, 0, sizeof(*times));
+    times->total_ms = total;
+    times->qkv_gemm_ms = acc[ST_QKV];
+    times->attention_ms = acc[ST_ATT];
+    times->out_gemm_ms = acc[ST_OUT];
+    times->layernorm_ms = acc[ST_LN];
+    times->head_gemm_ms = acc[ST_HEAD];
+    times->fusion_ms = acc[ST_FUSION];
+    times->refine_gemm_ms = acc[ST_REFINE];
+    times->scorer_ms = acc[ST_SCORER];
+    times->gemm_launches = tm.gemm_launches;
+    return 0;
+}
+
+extern "C" int iefvad_gemm_bias(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                                int32_t compute, void* stream) {
+    if (!A || !W || !bias || !C) return fail("iefvad_gemm_bias: null argument");
+    if (compute != IEFVAD_COMPUTE_F32) return fail("iefvad_gemm_bias: compute mode %d not built", compute);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS;
+    g.p[0].A = A; g.p[0].W = W; g.p[0].bias = bias; g.p[0].C = C;
+    Timer tm;
+    return launch_gemm(g, 1, (hipStream_t)stream, tm, ST_QKV);
+}

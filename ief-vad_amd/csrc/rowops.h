@@ -1,0 +1,146 @@
+// Row-wise (one wavefront per 768-wide snippet row) stages of the forward: LayerNorm, the
+// precision-weighted fusion, the scorer and the input cast.  All are HBM-bound streaming passes:
+// 16-byte coalesced loads (lane l owns columns 4l + 256 j, j = 0..2) and 64-lane shuffle reductions.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include "common.h"
+
+#define ROW_WAVES 4   // rows per 256-thread block
+
+// ---- LayerNorm(768), eps inside the sqrt, biased variance; optionally a second LayerNorm applied to
+// the result (the "whitening" LN that directly follows the last encoder LN, imf_vad.py:116-117,122-123).
+struct LnArgs {
+    const float* x[2];       // [N, 768] input (already x + attn_out from the out_proj epilogue)
+    float* y[2];             // [N, 768] output
+    const float* g1[2];      // first LN weight/bias
+    const float* b1[2];
+    const float* g2[2];      // second LN (nullable: skip)
+    const float* b2[2];
+    int nrows;
+    float eps;
+};
+
+__device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const float* b, int lane, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(s) * (1.0f / IEF_D);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[j][e] - mean;
+            v[j][e] = d;
+            ss += d * d;
+        }
+    const float var = wave_sum(ss) * (1.0f / IEF_D);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const f32x4 gv = *(const f32x4*)(g + 4 * lane + 256 * j);
+        const f32x4 bv = *(const f32x4*)(b + 4 * lane + 256 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * rstd * gv[e] + bv[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
+    const int mod = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= a.nrows) return;
+    const float* xp = a.x[mod] + (size_t)row * IEF_D + 4 * lane;
+    f32x4 v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = *(const f32x4*)(xp + 256 * j);
+    ln_row(v, a.g1[mod], a.b1[mod], lane, a.eps);
+    if (a.g2[mod] != nullptr) ln_row(v, a.g2[mod], a.b2[mod], lane, a.eps);
+    float* yp = a.y[mod] + (size_t)row * IEF_D + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *(f32x4*)(yp + 256 * j) = v[j];
+}
+
+// ---- Student-t / Gaussian precision weights + normalised inverse-variance fusion
+// (/root/reference/model/imf_vad.py:130-144):
+//   w_m = factor * exp(-logvar_m) ; den = w_i + w_e + eps ; n_m = w_m / den ; z = n_i*mu_i + n_e*mu_e
+// The literal formula is kept (including its inf/inf = NaN behaviour for logvar < -88.7).
+struct FusionArgs {
+    const float* mu_i; const float* lv_i; const float* mu_e; const float* lv_e;   // [N, 768]
+    float* n_i; float* n_e;     // [N, 768], nullable
+    float* z;                   // [N, 768]
+    float* n_i_mean; float* n_e_mean;   // [N], nullable: mean over D (test.py:131-136)
+    int nrows;
+    float factor, eps;
+};
+
+__global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= a.nrows) return;
+    const size_t base = (size_t)row * IEF_D + 4 * lane;
+    float si = 0.f, se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const size_t o = base + 256 * j;
+        const f32x4 mi = *(const f32x4*)(a.mu_i + o), li = *(const f32x4*)(a.lv_i + o);
+        const f32x4 me = *(const f32x4*)(a.mu_e + o), le = *(const f32x4*)(a.lv_e + o);
+        f32x4 ni, ne, z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float wi = __fmul_rn(a.factor, expf(-li[e]));
+            const float we = __fmul_rn(a.factor, expf(-le[e]));
+            const float den = __fadd_rn(__fadd_rn(wi, we), a.eps);
+            ni[e] = wi / den;
+            ne[e] = we / den;
+            z[e] = __fadd_rn(__fmul_rn(ni[e], mi[e]), __fmul_rn(ne[e], me[e]));
+            si += ni[e];
+            se += ne[e];
+        }
+        if (a.n_i) *(f32x4*)(a.n_i + o) = ni;
+        if (a.n_e) *(f32x4*)(a.n_e + o) = ne;
+        *(f32x4*)(a.z + o) = z;
+    }
+    if (a.n_i_mean || a.n_e_mean) {
+        si = wave_sum(si) * (1.0f / IEF_D);
+        se = wave_sum(se) * (1.0f / IEF_D);
+        if (lane == 0) {
+            if (a.n_i_mean) a.n_i_mean[row] = si;
+            if (a.n_e_mean) a.n_e_mean[row] = se;
+        }
+    }
+}
+
+// ---- scorer: logits = z . w_c + b_c  (classifier = Linear(768, 1), imf_vad.py:107,150)
+__global__ __launch_bounds__(256) void iefvad_scorer_kernel(const float* z, const float* w, const float* b,
+                                                             float* logits, int nrows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const float* zp = z + (size_t)row * IEF_D + 4 * lane;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const f32x4 zv = *(const f32x4*)(zp + 256 * j);
+        const f32x4 wv = *(const f32x4*)(w + 4 * lane + 256 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += zv[e] * wv[e];
+    }
+    s = wave_sum(s);
+    if (lane == 0) logits[row] = s + b[0];
+}
+
+// ---- input cast: the reference's `.to(torch.float)` (imf_vad.py:41-42) for fp16 / bf16 feature files
+template <typename T>
+__global__ __launch_bounds__(256) void iefvad_cast_kernel(const T* in0, const T* in1, float* out0, float* out1, size_t n) {
+    const T* in = blockIdx.y ? in1 : in0;
+    float* out = blockIdx.y ? out1 : out0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx * 4 < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = idx * 4;   // n is a multiple of 768
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)in[o + e];
+        *(f32x4*)(out + o) = v;
+    }
+}

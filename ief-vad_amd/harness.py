@@ -1,0 +1,266 @@
+"""Host-side callers of the forward: chunker, feature-file dataset, the evaluation loop and its
+multi-GPU sharding.  Counterparts of
+  * `process_split` / `pad`                       /root/reference/data/tools.py:81-86,100-114
+  * `UCF_Dataset` / `XD_Dataset` / `Shang_Dataset` /root/reference/data/dataset.py:8-127 (test mode)
+  * `test()`                                      /root/reference/test.py:46-212,
+                                                   train/ucf_test.py:16-216, train/xd_test.py:15-210
+  * `compute_ano_auc`                             /root/reference/test.py:332-348
+The model is any callable with the reference's `model(img, ev, padding_mask, text, lengths)` contract.
+"""
+from __future__ import annotations
+
+import csv
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+# per-dataset class keys of the reference's class-wise tables (/root/reference/test.py:20-43)
+CLASS_KEYS = {
+    'ucfcrime': ['Abuse', 'Arrest', 'Arson', 'Assault', 'Burglary', 'Explosion', 'Fighting', 'RoadAccidents',
+                 'Robbery', 'Shooting', 'Shoplifting', 'Stealing', 'Vandalism', 'Normal'],
+    'xd': ['normal', 'fighting', 'shooting', 'riot', 'abuse', 'car accident', 'explosion'],
+    'shang': ['car', 'chasing', 'fall', 'fighting', 'monocycle', 'robbery', 'running', 'skateboard',
+              'throwing_object', 'vehicle', 'vaudeville', 'normal'],
+    'msad': ['Normal', 'Assault', 'Explosion', 'Fighting', 'Fire', 'Object_falling', 'People_falling', 'Robbery',
+             'Shooting', 'Traffic_accident', 'Vandalism', 'Water_incident'],
+}
+# event-feature path rule: str.replace over the WHOLE path (dataset.py:36,67,112)
+EVENT_DIR = {'ucfcrime': 'event_thr_10', 'xd': 'event_thr_10', 'msad': 'event_thr_10', 'shang': 'event'}
+
+
+# ------------------------------------------------------------------------------------------------
+# chunker + dataset
+# ------------------------------------------------------------------------------------------------
+def process_split(feat: np.ndarray, length: int) -> Tuple[np.ndarray, int]:
+    """Test-time chunking (tools.py:100-114): len < length -> one zero-padded [length, D] block;
+    otherwise len//length + 1 blocks [n, length, D], the last zero padded -- an ALL-zero block when
+    len % length == 0.  dtype is preserved."""
+    n = int(feat.shape[0])
+    if n < length:
+        out = np.zeros((length, feat.shape[1]), dtype=feat.dtype)
+        out[:n] = feat
+        return out, n
+    nchunk = n // length + 1
+    out = np.zeros((nchunk * length, feat.shape[1]), dtype=feat.dtype)
+    out[:n] = feat
+    return out.reshape(nchunk, length, feat.shape[1]), n
+
+
+class VideoFeatureDataset(torch.utils.data.Dataset):
+    """Test-mode dataset over a `path,label` CSV of image-feature .npy files; the event file is found
+    with the reference's replace rule.  Items match the reference's:
+    (img [n,T,D] or [T,D], ev, label, length)."""
+
+    def __init__(self, clip_dim: int, file_path: str, dataset: str = 'ucfcrime'):
+        with open(file_path, newline='') as f:
+            rows = list(csv.DictReader(f))
+        self.paths = [r['path'] for r in rows]
+        self.labels = [r['label'] for r in rows]
+        self.clip_dim = clip_dim
+        self.event_dir = EVENT_DIR[dataset]
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, index):
+        p = self.paths[index]
+        img = np.load(p)
+        ev = np.load(p.replace('rgb', self.event_dir))
+        img, n = process_split(img, self.clip_dim)
+        ev, _ = process_split(ev, self.clip_dim)
+        return torch.tensor(img), torch.tensor(ev), self.labels[index], n
+
+
+def get_test_loader(args, dataset: Optional[str] = None):
+    """`DataLoader(test_dataset, batch_size=1, shuffle=False)` (data/__getter__.py:27,39-40,66)."""
+    ds = VideoFeatureDataset(args.visual_length, args.test_list, dataset or args.dataset)
+    return torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics (sklearn, exactly the calls the reference makes)
+# ------------------------------------------------------------------------------------------------
+def compute_ano_auc(classwise_gt, classwise_roc, repeat_factor=16, normal_keys=('Normal',)):
+    """test.py:332-348.  `normal_keys` covers the three variants of the filter: ('Normal',) in test.py:336,
+    ('Normal', 'normal') in ucf_test.py:340, ('normal',) in xd_test.py:334."""
+    from sklearn.metrics import roc_auc_score
+    gt_abnormal, pred_abnormal = [], []
+    for key in classwise_gt.keys():
+        if key not in normal_keys and len(classwise_gt[key]) > 0:
+            gt_abnormal.extend(np.concatenate(classwise_gt[key]).tolist())
+            pred_abnormal.extend(np.concatenate(classwise_roc[key]).tolist())
+    gt_abnormal = np.array(gt_abnormal)
+    pred_abnormal = np.array(pred_abnormal)
+    if len(np.unique(gt_abnormal)) > 1:
+        return roc_auc_score(gt_abnormal, np.repeat(pred_abnormal, repeat_factor))
+    return float('nan')
+
+
+def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np.ndarray, dataset: str,
+                    verbose: bool = True, normal_keys=('Normal',)) -> Dict[str, object]:
+    """Metric tail of test() (test.py:155-175): ROC-AUC / AP on the x16-repeated snippet scores, Ano-AUC
+    over the abnormal classes, per-class AUC/AP.  `scores` are per-video vectors in test-list order; gt
+    is indexed by the running snippet offset (test.py:129,153)."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    keys = CLASS_KEYS[dataset]
+    cw_pred = {k: [] for k in keys}
+    cw_gt = {k: [] for k in keys}
+    st = 0
+    for s, c in zip(scores, classes):
+        cw_pred[c].append(np.asarray(s))
+        cw_gt[c].append(gt[16 * st:16 * (st + len(s))])
+        st += len(s)
+    ap1 = np.concatenate([np.asarray(s) for s in scores]).tolist()
+    roc = roc_auc_score(gt, np.repeat(ap1, 16))
+    ap = average_precision_score(gt, np.repeat(ap1, 16))
+    ano = compute_ano_auc(cw_gt, cw_pred, normal_keys=normal_keys)
+    if verbose:
+        print("AUC1: {:.2f}  AP1: {:.2f}".format(roc * 100, ap * 100))
+        print("Ano-AUC: {:.2f}".format(ano * 100))
+    per_class = {}
+    for c in keys:
+        cls_pred = np.concatenate(cw_pred[c])   # raises on an empty class exactly as test.py:166-167 does
+        cls_gt = np.concatenate(cw_gt[c])
+        if len(cls_gt) == 0 or sum(cls_gt) == 0:
+            continue
+        c_roc = roc_auc_score(cls_gt, np.repeat(cls_pred, 16))
+        c_ap = average_precision_score(cls_gt, np.repeat(cls_pred, 16))
+        if verbose:
+            print(c, 'ROC: {:.2f}  AP: {:.2f}'.format(c_roc * 100, c_ap * 100))
+        per_class[c] = (c_roc, c_ap)
+    if verbose:
+        print('-------------------------------------------------')
+    return {"roc": roc, "ap": ap, "ano_auc": ano, "per_class": per_class}
+
+
+# ------------------------------------------------------------------------------------------------
+# the evaluation loop
+# ------------------------------------------------------------------------------------------------
+def _unpack_item(item, maxlen, dataset, label_map):
+    """Shape rule of test.py:77-88 applied to one DataLoader item (batch_size=1)."""
+    img = item[0].squeeze(0)
+    ev = item[1].squeeze(0)
+    cls = item[2][0] if isinstance(item[2], (list, tuple)) else item[2]
+    if dataset == 'xd' and label_map is not None:
+        cls = label_map[cls.split('-')[0]]            # xd_test.py:68
+    length = int(item[3])
+    if length < maxlen:
+        img = img.unsqueeze(0)
+        ev = ev.unsqueeze(0)
+    if torch.isnan(img).any():                        # conditional nan_to_num, test.py:90-95
+        img = torch.nan_to_num(img, nan=0.0)
+    if torch.isnan(ev).any():
+        ev = torch.nan_to_num(ev, nan=0.0)
+    return img, ev, cls, length
+
+
+def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
+                 label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True):
+    """Per-video sigmoid scores and mean fusion weights, in loader order.
+
+    batch_chunks == 0: one forward per video with B = that video's chunk count -- the reference's call
+    pattern (test.py:76-117).  batch_chunks > 0: chunks of consecutive videos are packed into one
+    forward of up to `batch_chunks` chunks; legal because chunks are independent batch rows
+    (imf_vad.py:115 attends within a chunk), and the trailing all-zero chunk of a len % 256 == 0 video,
+    whose rows the reference slices away (test.py:121), is not computed when `skip_empty_chunks`."""
+    scores: List[np.ndarray] = []
+    wi_means: List[np.ndarray] = []
+    we_means: List[np.ndarray] = []
+    classes: List[str] = []
+    pend: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
+    pend_chunks = 0
+
+    def flush():
+        nonlocal pend, pend_chunks
+        if not pend:
+            return
+        dt = torch.float32 if len({p[0].dtype for p in pend}) > 1 else pend[0][0].dtype
+        img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device)
+        ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device)
+        out = model(img, ev, None, None, None)
+        logits = out['logits'].reshape(-1)
+        if 'w_i_mean' in out:
+            wi, we = out['w_i_mean'].reshape(-1), out['w_e_mean'].reshape(-1)
+        else:
+            wi = out['w_i'].reshape(-1, out['w_i'].shape[-1]).mean(dim=-1)     # test.py:131-136
+            we = out['w_e'].reshape(-1, out['w_e'].shape[-1]).mean(dim=-1)
+        prob = torch.sigmoid(logits).float().cpu().numpy()
+        wi, we = wi.float().cpu().numpy(), we.float().cpu().numpy()
+        off = 0
+        for ci, _, n in pend:
+            scores.append(prob[off:off + n].copy())          # logits1[0:len_cur] -> sigmoid, test.py:119-121
+            wi_means.append(wi[off:off + n].copy())
+            we_means.append(we[off:off + n].copy())
+            off += ci.shape[0] * maxlen
+        pend, pend_chunks = [], 0
+
+    with torch.no_grad():
+        for item in test_loader:
+            img, ev, cls, n = _unpack_item(item, maxlen, dataset, label_map)
+            classes.append(cls)
+            if batch_chunks > 0 and skip_empty_chunks and n >= maxlen and n % maxlen == 0:
+                img, ev = img[:-1], ev[:-1]               # the all-zero chunk (tools.py:105-112)
+            pend.append((img, ev, n))
+            pend_chunks += img.shape[0]
+            if batch_chunks <= 0 or pend_chunks >= batch_chunks:
+                flush()
+        flush()
+    return scores, classes, wi_means, we_means
+
+
+def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,
+         batch_chunks: int = 0, normal_keys=('Normal',)):
+    """Same positional signature and return value as the reference's `test()` (test.py:46-56;
+    ucf_test.py:16-26; xd_test.py passes `label_map` as an extra positional, :23).
+    Returns (ROC1, AP1) -- or (ROC1, AP1, attn_weights, labels) when attn=True, where attn_weights is the
+    empty list the reference also returns (it never fills it, test.py:73,209-210)."""
+    model.to(device)
+    model.eval()
+    scores, classes, wi, we = score_loader(model, test_loader, maxlen, device, args.dataset, label_map, batch_chunks)
+    res = evaluate_scores(scores, classes, gt, args.dataset, verbose=True, normal_keys=normal_keys)
+    test.last_result = dict(res, scores=scores, classes=classes, w_i_mean=wi, w_e_mean=we)
+    if vis:
+        print("[iefvad_amd] vis=True: plotting (test.py:177-207) is outside the hot-path scope; skipped")
+    if attn:
+        return res["roc"], res["ap"], [], classes
+    return res["roc"], res["ap"]
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU: contiguous, snippet-balanced shards + one ordered score gather
+# ------------------------------------------------------------------------------------------------
+def partition_by_snippets(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Cut the ordered test list into `world` contiguous [begin, end) video ranges with ~equal snippet
+    counts.  Contiguity keeps rank-order concatenation equal to the reference's sequential order, on
+    which the gt offsets depend (test.py:129,153)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    total = int(lengths.sum())
+    cum = np.concatenate([[0], np.cumsum(lengths)])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        j = int(np.searchsorted(cum, target, side='left'))
+        if j > 0 and abs(cum[j - 1] - target) <= abs(cum[min(j, len(cum) - 1)] - target):
+            j -= 1
+        j = min(max(j, cuts[-1]), len(lengths))
+        cuts.append(j)
+    cuts.append(len(lengths))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_scores(local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather variable-length fp32 score vectors in rank order (one padded all_gather; counts first).
+    Backend "nccl" is RCCL over xGMI on ROCm; "gloo" serves the CPU tests."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts) if counts else 0
+    buf = torch.zeros(mx, dtype=torch.float32, device=local.device)
+    buf[:local.numel()] = local.reshape(-1).float()
+    out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])

@@ -1,0 +1,113 @@
+"""ctypes binding of libiefvad.so (the C ABI declared in include/iefvad.h).
+
+Loading never falls back to anything: if the shared library is missing or does not export a
+symbol the header declares, `load_library()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiefvad.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+MAX_LAYERS = 8
+MAX_STEPS = 64
+NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
+IN_F32, IN_F16, IN_BF16 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
+
+# every symbol include/iefvad.h declares
+SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_workspace_bytes",
+           "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_last_error", "iefvad_destroy"]
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("embed_dim", C.c_int32), ("seq_len", C.c_int32),
+                ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("num_steps", C.c_int32),
+                ("noise_model", C.c_int32), ("compute", C.c_int32), ("lambda_ref", C.c_float),
+                ("nu", C.c_float), ("epsilon", C.c_float), ("micro_batch", C.c_int32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("in_proj_w", (_fp * MAX_LAYERS) * 2), ("in_proj_b", (_fp * MAX_LAYERS) * 2),
+                ("out_proj_w", (_fp * MAX_LAYERS) * 2), ("out_proj_b", (_fp * MAX_LAYERS) * 2),
+                ("norm_w", (_fp * MAX_LAYERS) * 2), ("norm_b", (_fp * MAX_LAYERS) * 2),
+                ("whiten_w", _fp * 2), ("whiten_b", _fp * 2),
+                ("mu_w", _fp * 2), ("mu_b", _fp * 2), ("logvar_w", _fp * 2), ("logvar_b", _fp * 2),
+                ("ref_w1", _fp * MAX_STEPS), ("ref_b1", _fp * MAX_STEPS),
+                ("ref_w2", _fp * MAX_STEPS), ("ref_b2", _fp * MAX_STEPS),
+                ("cls_w", _fp), ("cls_b", _fp)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("fused", _fp), ("logits", _fp), ("image_mu", _fp), ("event_mu", _fp),
+                ("image_logvar", _fp), ("event_logvar", _fp), ("w_i", _fp), ("w_e", _fp),
+                ("w_i_mean", _fp), ("w_e_mean", _fp)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("qkv_gemm_ms", C.c_float), ("attention_ms", C.c_float),
+                ("out_gemm_ms", C.c_float), ("layernorm_ms", C.c_float), ("head_gemm_ms", C.c_float),
+                ("fusion_ms", C.c_float), ("refine_gemm_ms", C.c_float), ("scorer_ms", C.c_float),
+                ("gemm_launches", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libiefvad.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libiefvad.so and declare prototypes.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(hipcc --offload-arch=gfx950); there is no CPU fallback for this path")
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise RuntimeError(f"libiefvad.so does not export {s}")
+    lib.iefvad_abi_version.restype = C.c_int
+    lib.iefvad_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.iefvad_create.restype = C.c_int
+    lib.iefvad_set_weights.argtypes = [C.c_void_p, C.POINTER(Weights), C.c_void_p]
+    lib.iefvad_set_weights.restype = C.c_int
+    lib.iefvad_workspace_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.iefvad_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_size_t, C.POINTER(Outputs), C.c_void_p]
+    lib.iefvad_forward.restype = C.c_int
+    lib.iefvad_forward_timed.argtypes = lib.iefvad_forward.argtypes + [C.POINTER(StageTimes)]
+    lib.iefvad_forward_timed.restype = C.c_int
+    lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p]
+    lib.iefvad_gemm_bias.restype = C.c_int
+    lib.iefvad_last_error.restype = C.c_char_p
+    lib.iefvad_destroy.argtypes = [C.c_void_p]
+    lib.iefvad_destroy.restype = None
+    if lib.iefvad_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libiefvad.so ABI {lib.iefvad_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().iefvad_last_error().decode("utf-8", "replace")

@@ -1,0 +1,282 @@
+"""Drop-in `MMFMIL` for the reference's evaluation loops, backed by libiefvad.so.
+
+Mirrors the interface of /root/reference/model/imf_vad.py:
+  * constructor signature of `MMFMIL` (:6-18) and the hyper-parameters it forwards (:30-38);
+  * `state_dict()` keys and shapes so `load_state_dict(torch.load(ckpt))`
+    (/root/reference/test.py:377-378) works unchanged;
+  * `forward(img, ev, padding_mask, text, lengths, return_attn=False) -> dict` with the eight keys of
+    :152-161; `padding_mask`, `text`, `lengths`, `return_attn` are accepted and ignored (:40-44);
+  * attribute `model.temporal.nu` read by the training loss (/root/reference/train/ucf_train.py:94-95);
+  * `ValueError` for an unsupported `noise_model`, raised at forward time (:137-138).
+
+The modules below only HOLD parameters (same names, shapes and default initialisation as the
+torch.nn modules the reference instantiates); no torch op computes the forward.  Inputs must live
+on a HIP device: there is no CPU path, a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+
+_IN_DTYPES = {torch.float32: _lib.IN_F32, torch.float16: _lib.IN_F16, torch.bfloat16: _lib.IN_BF16}
+OUTPUT_KEYS = ("fused", "logits", "image_mu", "event_mu", "image_logvar", "event_logvar", "w_i", "w_e")
+
+
+class _LinearParams(nn.Module):
+    """Parameter holder with nn.Linear's names, shapes and default init (kaiming-uniform a=sqrt(5))."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _AttentionParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's packed layout: in_proj_weight [3D, D] in (q, k, v)
+    order, in_proj_bias [3D], out_proj.{weight,bias}; same init order as torch (out_proj first, then
+    xavier-uniform in_proj, zero biases) so a seeded construction reproduces the reference's weights."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * dim))
+        self.out_proj = _LinearParams(dim, dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class _RefinementBlockParams(nn.Module):
+    """Sequential(Linear, ReLU, Linear): parameters live at indices 0 and 2 (imf_vad.py:97-104)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.add_module("0", _LinearParams(dim, dim))
+        self.add_module("2", _LinearParams(dim, dim))
+
+
+class FusionParams(nn.Module):
+    """Parameters and hyper-parameters of MultiModal_Fusion_Attn_Iter (imf_vad.py:48-107), registered
+    in the reference's order."""
+
+    def __init__(self, embed_dim, num_layers=2, num_heads=8, dropout=0.1, num_refinement_steps=3,
+                 lambda_ref=0.5, noise_model="StudentT", nu=5, epsilon=1e-8):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.num_refinement_steps = num_refinement_steps
+        self.lambda_ref = lambda_ref
+        self.noise_model = noise_model
+        self.nu = nu
+        self.epsilon = epsilon
+        self.image_attn_layers = nn.ModuleList([_AttentionParams(embed_dim) for _ in range(num_layers)])
+        self.image_norms = nn.ModuleList([_LayerNormParams(embed_dim) for _ in range(num_layers)])
+        self.event_attn_layers = nn.ModuleList([_AttentionParams(embed_dim) for _ in range(num_layers)])
+        self.event_norms = nn.ModuleList([_LayerNormParams(embed_dim) for _ in range(num_layers)])
+        self.whiten_image = _LayerNormParams(embed_dim)
+        self.whiten_event = _LayerNormParams(embed_dim)
+        self.image_mu = _LinearParams(embed_dim, embed_dim)
+        self.event_mu = _LinearParams(embed_dim, embed_dim)
+        self.image_logvar = _LinearParams(embed_dim, embed_dim)
+        self.event_logvar = _LinearParams(embed_dim, embed_dim)
+        if num_refinement_steps == 0:
+            self.refinement_blocks = nn.ModuleList([nn.Identity()])
+        else:
+            self.refinement_blocks = nn.ModuleList(
+                [_RefinementBlockParams(embed_dim) for _ in range(num_refinement_steps)])
+        self.classifier = _LinearParams(embed_dim, 1)
+
+
+class MMFMIL(nn.Module):
+    """Same constructor as the reference's MMFMIL (/root/reference/model/imf_vad.py:6-18).
+
+    Extra, keyword-only knobs (not in the reference):
+      outputs      "full" (default; all eight tensors, the drop-in behaviour) or "scores"
+                   (only `logits` plus the per-row means `w_i_mean`, `w_e_mean`; nothing 768-wide
+                   is written to HBM).
+      micro_batch  chunks per internal pass of the library (0 = library default).
+    """
+
+    def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
+                 visual_layers: int, attn_window: int, prompt_prefix: int, prompt_postfix: int, device, args,
+                 *, outputs: str = "full", micro_batch: int = 0):
+        super().__init__()
+        self.num_class = num_class
+        self.visual_length = visual_length
+        self.visual_width = visual_width
+        self.embed_dim = embed_dim
+        self.attn_window = attn_window
+        self.prompt_prefix = prompt_prefix
+        self.prompt_postfix = prompt_postfix
+        self.device = device
+        self.temporal = FusionParams(embed_dim, num_layers=args.visual_layers, num_heads=args.visual_head,
+                                     num_refinement_steps=args.num_refinement_steps, lambda_ref=args.lambda_ref,
+                                     noise_model=args.noise_model, nu=args.nu)
+        if outputs not in ("full", "scores"):
+            raise ValueError("outputs must be 'full' or 'scores'")
+        self.outputs = outputs
+        self.micro_batch = micro_batch
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_key = None
+        self._weights_sig = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.last_stage_times: Optional[dict] = None
+
+    # ------------------------------------------------------------------ library plumbing
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load_library().iefvad_destroy(self._handle)
+            self._handle = None
+            self._handle_key = None
+            self._weights_sig = None
+
+    def _noise_code(self) -> int:
+        nm = self.temporal.noise_model
+        if nm == "Gaussian":
+            return _lib.NOISE_GAUSSIAN
+        if nm == "StudentT":
+            return _lib.NOISE_STUDENT_T
+        raise ValueError("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.")   # imf_vad.py:137-138
+
+    def _ensure_handle(self, device: torch.device):
+        t = self.temporal
+        key = (device.index, t.embed_dim, self.visual_length, t.num_heads, t.num_layers, t.num_refinement_steps,
+               self._noise_code(), float(t.lambda_ref), float(t.nu), float(t.epsilon), int(self.micro_batch))
+        if self._handle is not None and key == self._handle_key:
+            return
+        self._release()
+        lib = _lib.load_library()
+        cfg = _lib.Config(abi_version=_lib.ABI_VERSION, embed_dim=t.embed_dim, seq_len=self.visual_length,
+                          num_heads=t.num_heads, num_layers=t.num_layers, num_steps=t.num_refinement_steps,
+                          noise_model=self._noise_code(), compute=_lib.COMPUTE_F32, lambda_ref=float(t.lambda_ref),
+                          nu=float(t.nu), epsilon=float(t.epsilon), micro_batch=int(self.micro_batch))
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.iefvad_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("iefvad_create: " + _lib.last_error())
+        self._handle, self._handle_key = h, key
+
+    def _ensure_weights(self, device: torch.device, stream: int):
+        t = self.temporal
+        params = list(t.parameters())
+        for p in params:
+            if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("MMFMIL parameters must be contiguous fp32 tensors on the input's device "
+                                   f"({device}); call model.to(device)")
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        if sig == self._weights_sig:
+            return
+        w = _lib.Weights()
+        for m, name in enumerate(("image", "event")):
+            attn = getattr(t, f"{name}_attn_layers")
+            norms = getattr(t, f"{name}_norms")
+            for l in range(t.num_layers):
+                w.in_proj_w[m][l] = attn[l].in_proj_weight.data_ptr()
+                w.in_proj_b[m][l] = attn[l].in_proj_bias.data_ptr()
+                w.out_proj_w[m][l] = attn[l].out_proj.weight.data_ptr()
+                w.out_proj_b[m][l] = attn[l].out_proj.bias.data_ptr()
+                w.norm_w[m][l] = norms[l].weight.data_ptr()
+                w.norm_b[m][l] = norms[l].bias.data_ptr()
+            wh = getattr(t, f"whiten_{name}")
+            w.whiten_w[m], w.whiten_b[m] = wh.weight.data_ptr(), wh.bias.data_ptr()
+            mu, lv = getattr(t, f"{name}_mu"), getattr(t, f"{name}_logvar")
+            w.mu_w[m], w.mu_b[m] = mu.weight.data_ptr(), mu.bias.data_ptr()
+            w.logvar_w[m], w.logvar_b[m] = lv.weight.data_ptr(), lv.bias.data_ptr()
+        for k in range(t.num_refinement_steps):
+            blk = t.refinement_blocks[k]
+            l1, l2 = getattr(blk, "0"), getattr(blk, "2")
+            w.ref_w1[k], w.ref_b1[k] = l1.weight.data_ptr(), l1.bias.data_ptr()
+            w.ref_w2[k], w.ref_b2[k] = l2.weight.data_ptr(), l2.bias.data_ptr()
+        w.cls_w, w.cls_b = t.classifier.weight.data_ptr(), t.classifier.bias.data_ptr()
+        rc = _lib.load_library().iefvad_set_weights(self._handle, C.byref(w), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("iefvad_set_weights: " + _lib.last_error())
+        self._weights_sig = sig
+
+    # ------------------------------------------------------------------ forward
+    def _prepare_input(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype not in _IN_DTYPES:
+            x = x.to(torch.float)        # imf_vad.py:41-42 for fp64 / integer inputs
+        return x.contiguous()
+
+    def forward(self, img_visual, ev_visual, padding_mask=None, text=None, lengths=None, return_attn=False,
+                *, timed: bool = False) -> Dict[str, torch.Tensor]:
+        if self.training:
+            raise RuntimeError("iefvad_amd.MMFMIL is inference-only (the reference applies attention dropout in "
+                               "train mode); call model.eval() first")
+        self._noise_code()   # ValueError for an unsupported noise_model, as the reference raises
+        if not (img_visual.is_cuda and ev_visual.is_cuda):
+            raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback "
+                               "(move the inputs with .to('cuda'))")
+        if img_visual.shape != ev_visual.shape or img_visual.dim() != 3:
+            raise ValueError(f"expected two [B, T, D] tensors of equal shape, got {tuple(img_visual.shape)} and "
+                             f"{tuple(ev_visual.shape)}")
+        B, T, D = img_visual.shape
+        if T != self.visual_length or D != self.temporal.embed_dim:
+            raise ValueError(f"expected [B, {self.visual_length}, {self.temporal.embed_dim}] inputs, got [B, {T}, {D}]")
+        device = img_visual.device
+        img = self._prepare_input(img_visual)
+        ev = self._prepare_input(ev_visual)
+        if ev.dtype != img.dtype:
+            img, ev = img.to(torch.float), ev.to(torch.float)
+        lib = _lib.load_library()
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            self._ensure_handle(device)
+            self._ensure_weights(device, stream)
+            need = lib.iefvad_workspace_bytes(self._handle, B)
+            if self._workspace is None or self._workspace.device != device or self._workspace.numel() < need:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+            N = B * T
+            f32 = dict(dtype=torch.float32, device=device)
+            res: Dict[str, torch.Tensor] = {}
+            o = _lib.Outputs()
+            res["logits"] = torch.empty(B, T, 1, **f32)
+            o.logits = res["logits"].data_ptr()
+            if self.outputs == "full":
+                for k in OUTPUT_KEYS:
+                    if k != "logits":
+                        res[k] = torch.empty(B, T, D, **f32)
+                        setattr(o, k, res[k].data_ptr())
+            else:
+                res["w_i_mean"] = torch.empty(B, T, **f32)
+                res["w_e_mean"] = torch.empty(B, T, **f32)
+                o.w_i_mean, o.w_e_mean = res["w_i_mean"].data_ptr(), res["w_e_mean"].data_ptr()
+            args = (self._handle, C.c_void_p(img.data_ptr()), C.c_void_p(ev.data_ptr()), _IN_DTYPES[img.dtype], B,
+                    C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), C.byref(o), C.c_void_p(stream))
+            if timed:
+                st = _lib.StageTimes()
+                rc = lib.iefvad_forward_timed(*args, C.byref(st))
+                self.last_stage_times = st.as_dict()
+            else:
+                rc = lib.iefvad_forward(*args)
+            if rc != 0:
+                raise RuntimeError("iefvad_forward: " + _lib.last_error())
+        if self.outputs == "full":
+            return {k: res[k] for k in OUTPUT_KEYS}   # the reference's key order
+        return res

@@ -1,0 +1,147 @@
+"""Parity of the HIP path (through the C ABI of libiefvad.so) against the golden vectors captured from
+the reference and against the CPU oracle.  Needs a real MI355X: run with `-m gpu`."""
+import argparse
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import synth
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(L, K, lam, noise, nu, sd, **kw):
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=lam,
+                              noise_model=noise, nu=nu)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, **kw)
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval()
+
+
+def run(model, img, ev):
+    with torch.no_grad():
+        out = model(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_native_library_is_loaded():
+    lib = iefvad_amd.lib.load_library()
+    assert lib.iefvad_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libiefvad.so" in f.read()
+
+
+def test_gemm_kernel_matches_fp64():
+    """C = A W^T + b on the fp32 MFMA kernel vs an fp64 host product; asymmetric operands catch a
+    transposed accumulator map.  Tolerance: fp32 k-ordered fma chain, K=768 -> ~1e-7 * sum|a*b|."""
+    lib = iefvad_amd.lib.load_library()
+    rng = np.random.default_rng(0)
+    for (M, N, K) in [(256, 768, 768), (512, 2304, 768), (128, 128, 32)]:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = rng.standard_normal((N, K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        dA, dW, db = (torch.from_numpy(x).cuda() for x in (A, W, b))
+        dC = torch.empty(M, N, device="cuda")
+        rc = lib.iefvad_gemm_bias(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), dC.data_ptr(), M, N, K, 0,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, iefvad_amd.lib.last_error()
+        torch.cuda.synchronize()
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+        err = np.abs(dC.cpu().numpy() - ref).max()
+        assert err < 2e-4 * np.sqrt(K / 768.0) + 1e-5, (M, N, K, err)
+
+
+@pytest.mark.parametrize("name", H.golden_cases())
+def test_forward_matches_reference_golden(name):
+    g, cfg, sd, img, ev = H.load_case(name)
+    model = make_model(cfg["L"], cfg["K"], cfg["lam"], cfg["noise"], cfg["nu"], sd)
+    out = run(model, img, ev)
+    assert list(out.keys()) == list(iefvad_amd.OUTPUT_KEYS)
+    assert out["logits"].shape == (cfg["B"], 256, 1) and out["fused"].shape == (cfg["B"], 256, 768)
+    errs = H.compare_outputs(out, g)
+    print(name, errs)
+
+
+def test_scores_only_mode_matches_full_and_golden():
+    g, cfg, sd, img, ev = H.load_case("base_k10_student8")
+    full = run(make_model(cfg["L"], cfg["K"], cfg["lam"], cfg["noise"], cfg["nu"], sd), img, ev)
+    lite = run(make_model(cfg["L"], cfg["K"], cfg["lam"], cfg["noise"], cfg["nu"], sd, outputs="scores"), img, ev)
+    assert set(lite.keys()) == {"logits", "w_i_mean", "w_e_mean"}
+    assert np.array_equal(lite["logits"], full["logits"])          # same kernels, same order -> bit equal
+    assert np.abs(lite["w_i_mean"] - g["w_i_mean"]).max() < 2e-6
+    assert np.abs(lite["w_e_mean"] - g["w_e_mean"]).max() < 2e-6
+
+
+def test_micro_batching_is_bit_identical():
+    """Chunks are independent batch rows: B=5 in one pass == the same chunks in passes of 2."""
+    sd = synth.make_state_dict(31, 768, 2, 3)
+    img, ev = synth.make_inputs(32, 5)
+    a = run(make_model(2, 3, 0.5, "StudentT", 8, sd), img, ev)
+    b = run(make_model(2, 3, 0.5, "StudentT", 8, sd, micro_batch=2), img, ev)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    c = run(make_model(2, 3, 0.5, "StudentT", 8, sd), img[3:4], ev[3:4])
+    assert np.array_equal(a["logits"][3:4], c["logits"])
+
+
+def test_forward_vs_oracle_larger_batch():
+    """B=16 (4096 snippets) against the CPU oracle on the same seeded inputs."""
+    sd = synth.make_state_dict(41, 768, 2, 10)
+    img, ev = synth.make_inputs(42, 16)
+    out = run(make_model(2, 10, 0.5, "StudentT", 8, sd), img, ev)
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig())
+    for k in iefvad_amd.OUTPUT_KEYS:
+        d = np.abs(out[k] - ref[k].numpy()).max()
+        assert d <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), (k, d)
+    ds = np.abs(H.sigmoid(out["logits"]) - H.sigmoid(ref["logits"].numpy())).max()
+    assert ds <= H.TOL_SIGMOID
+
+
+def test_bf16_and_fp64_inputs_follow_to_float():
+    sd = synth.make_state_dict(51, 768, 1, 1)
+    img, ev = synth.make_inputs(52, 1)
+    model = make_model(1, 1, 0.5, "StudentT", 8, sd)
+    cfg = orc.OracleConfig(num_layers=1, num_refinement_steps=1)
+    for dt in (torch.bfloat16, torch.float64):
+        ti, te = torch.from_numpy(img).to(dt), torch.from_numpy(ev).to(dt)
+        with torch.no_grad():
+            out = model(ti.cuda(), te.cuda(), None, None, None)
+        ref = orc.forward(sd, ti, te, cfg)
+        assert (out["logits"].cpu() - ref["logits"]).abs().max().item() < H.TOL_LOGIT
+
+
+def test_error_paths():
+    sd = synth.make_state_dict(61, 768, 1, 0)
+    model = make_model(1, 0, 0.5, "StudentT", 8, sd)
+    x = torch.zeros(1, 256, 768)
+    with pytest.raises(RuntimeError):           # CPU tensors: no fallback
+        model(x, x, None, None, None)
+    with pytest.raises(ValueError):             # wrong T
+        model(torch.zeros(1, 128, 768).cuda(), torch.zeros(1, 128, 768).cuda(), None, None, None)
+    model.temporal.noise_model = "Laplace"
+    with pytest.raises(ValueError):             # imf_vad.py:137-138
+        model(x.cuda(), x.cuda(), None, None, None)
+    model.temporal.noise_model = "StudentT"
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(x.cuda(), x.cuda(), None, None, None)
+
+
+def test_literal_overflow_semantics():
+    """logvar < -88.7 on both modalities makes exp(-logvar) overflow: the reference's literal formula
+    gives inf/inf = NaN (imf_vad.py:135-142).  Parity mode keeps it."""
+    sd = synth.make_state_dict(71, 768, 1, 0)
+    for m in ("image", "event"):
+        sd[f"temporal.{m}_logvar.weight"].zero_()
+        sd[f"temporal.{m}_logvar.bias"].fill_(-100.0)
+    img, ev = synth.make_inputs(72, 1)
+    out = run(make_model(1, 0, 0.5, "StudentT", 8, sd), img, ev)
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_layers=1, num_refinement_steps=0))
+    assert np.isnan(ref["w_i"].numpy()).all() and np.isnan(out["w_i"]).all()
+    assert np.isnan(out["logits"]).all()
