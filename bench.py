@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- snippets/sec of the IEF-VAD fusion-inference forward on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (MMFMIL.forward through libiefvad.so, scores-only outputs) over
+one batch of synthetic [B, T=256, d=768] fp32 image + event feature blocks that are already resident
+in HBM, followed -- when N > 1 -- by the single RCCL all-gather of per-snippet scores.  Default batch:
+BASELINE.json config 4's B = 8192 chunks (2,097,152 snippets) PER GPU; every rank holds its own
+blocks (videos shard embarrassingly), so scaling is weak and `value` is the whole-job
+aggregate.  Weights are seeded synthetic tensors of the reference architecture (K=10, nu=8, StudentT).
+
+The JSON line also carries
+  roofline      the dense-projection GEMM kernel (iefvad_gemm_f32_kernel, >90 % of device time):
+                algorithmic GEMM FLOPs of a step / sum of that kernel's launch durations in the step,
+                timed with hipEvents on the launch stream inside the timed region, against the exact-fp32
+                MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
+  cpu_baseline  the CPU oracle (oracle/iefvad_oracle.py, torch CPU ops on all host cores) timed on a
+                bounded sample of the same workload, rank 0 at N=1 only.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+T, D, H, L, K_STEPS = 256, 768, 8, 2, 10
+GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D) + K_STEPS * 2 * (2 * D * D)
+TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
+PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--chunks", type=int, default=8192, help="chunks [256,768] per GPU per step")
+    p.add_argument("--micro-batch", type=int, default=0, help="chunks per internal pass (0 = library default)")
+    p.add_argument("--outputs", default="scores", choices=["scores", "full"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    return p.parse_args()
+
+
+def cpu_baseline(sd, seconds):
+    """The oracle (CPU restatement of the reference forward) on the host cores: B=8 chunks per call, the
+    best-case batched pattern of SURVEY.md 8d, repeated for ~`seconds`."""
+    import numpy as np
+    from iefvad_amd import synth
+    from oracle import iefvad_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    model = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K_STEPS, nu=8))
+    img, ev = synth.make_inputs(1234, 8)
+    img, ev = torch.from_numpy(img), torch.from_numpy(ev)
+    model(img, ev)                                   # warm-up
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        model(img, ev)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 8 * T / med, "unit": "snippets/s", "cores": cores, "kind": "port",
+            "sample": f"oracle forward, B=8 chunks (2048 snippets) per call, median of {len(times)} calls, fp32"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
+
+    import iefvad_amd
+    from iefvad_amd import synth
+    from iefvad_amd.harness import gather_scores
+    margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K_STEPS, lambda_ref=0.5,
+                               noise_model="StudentT", nu=8)
+    sd = synth.make_state_dict(0, D, L, K_STEPS)
+    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
+                              micro_batch=a.micro_batch)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    B = a.chunks
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    img = torch.randn(B, T, D, device=dev, generator=gen) * 0.45
+    ev = torch.randn(B, T, D, device=dev, generator=gen) * 0.45
+
+    stage = {}
+
+    def step():
+        with torch.no_grad():
+            out = model(img, ev, None, None, None, timed=True)
+        for k, v in model.last_stage_times.items():
+            stage[k] = stage.get(k, 0.0) + v
+        scores = out["logits"].reshape(-1)
+        if world > 1:
+            scores = gather_scores(scores)
+        return scores
+
+    for _ in range(a.warmup):
+        step()
+    stage.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        scores = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert scores.numel() == world * B * T and bool(torch.isfinite(scores).all())
+
+    if rank == 0:
+        snippets = world * B * T * a.steps
+        value = snippets / dt
+        gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / a.steps
+        launches = stage["gemm_launches"] / a.steps
+        gemm_flops = GEMM_FLOPS_PER_SNIPPET * B * T                     # per step, this rank
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        line = {
+            "metric": "snippets/sec at [B,T=256,d=768]", "value": value, "unit": "snippets/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic [B={B},T=256,d=768] fp32 image+event blocks per GPU resident in HBM "
+                                   f"(BASELINE config 4 batch), K=10 nu=8 StudentT, seeded random weights, "
+                                   f"outputs={a.outputs}",
+                       "chunks_per_gpu": B, "snippets_per_step": world * B * T,
+                       "parallelism": f"video-sharded x{world}, score all-gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "iefvad_gemm_f32_kernel",
+                         "launches_per_step": launches,
+                         "avg_launch_ms": gemm_ms / launches,
+                         "flops_per_launch": gemm_flops / launches},
+            "stage_ms_per_step": {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")},
+            "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,9 +15,9 @@
 // the K summation differs from a sequential loop, the set of products does not.
 // LDS image: [row][32 floats] with the 16-byte chunk index XORed by (row>>1)&7, which makes the
 // four 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (conflict-free).
-// Staging is register based (global_load_dwordx4 -> ds_write_b128), issued one k-tile ahead so the
-// loads fly under the 64 MFMAs of the current tile; LDS is double buffered, one barrier per tile.
-// 64 KB LDS + <=128 VGPRs -> 2 blocks per CU, so one block's barrier wait hides under the other's MFMAs.
+// Staging is LDS-DMA (global_load_lds_dwordx4, see the comment at the main loop), one k-tile ahead;
+// LDS is double buffered, one barrier per tile.
+// 64 KB LDS + <256 VGPRs -> 2 blocks per CU, so one block's barrier wait hides under the other's MFMAs.
 #pragma once
 #include "common.h"
 
@@ -69,9 +69,6 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) 
 
     // staging: thread t moves chunk (row = (t>>3) + 32 j, ch = t&7), j = 0..3, of both tiles
     const int srow = t >> 3, sch = t & 7;
-    const float* gA = P.A + (size_t)(m0 + srow) * lda + sch * 4;
-    const float* gW = P.W + (size_t)(n0 + srow) * K + sch * 4;
-    const int sdst = srow * GEMM_BK + ((sch ^ ((srow >> 1) & 7)) << 2);   // (row>>1)&7 is j-invariant
 
     // fragment read offsets (floats) inside a tile image
     const int fsw = (i >> 1) & 7;
@@ -90,70 +87,101 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    f32x4 ra[4], rw[4];
+    // Staging: LDS-DMA (global_load_lds_dwordx4), one k-tile ahead, LDS double buffered.  One wave
+    // instruction moves 64 x 16 B = 8 rows x 128 B straight into LDS (no VGPR round trip, no ds_write);
+    // the LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address and
+    // again on the fragment read.  Thread t moves chunk (row = (t>>3) + 32 j, slot = t&7) for j = 0..3 of
+    // both operand tiles; the eight DMAs of tile kt+1 are issued at the top of tile kt, so they have the
+    // whole tile (64 MFMAs per wave) to land before the vmcnt(0) + barrier that ends it.
     const int nk = K / GEMM_BK;
-    // prologue: tile 0 -> LDS buffer 0
+    const int ssw = (srow >> 1) & 7;                          // (row>>1)&7, j-invariant
+    // buffer addressing: SGPR descriptor + per-lane byte offset that never changes + scalar byte offset
+    // that walks j and the k-tile -> the main loop spends no VALU instruction on addresses.
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
+                                                       (int)((GEMM_BM - 1) * lda + K) * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
+                                                       (int)((GEMM_BN - 1) * K + K) * 4, 0x00020000);
+    const int voA = (srow * lda + ((sch ^ ssw) << 2)) * 4;
+    const int voW = (srow * K + ((sch ^ ssw) << 2)) * 4;
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * GEMM_BK;   // wave-uniform LDS offset (floats)
+#define GLDS16(rs, vo, so, lp)                                                                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        ra[j] = *(const f32x4*)(gA + (size_t)(32 * j) * lda);
-        rw[j] = *(const f32x4*)(gW + (size_t)(32 * j) * K);
+        GLDS16(rsA, voA, (32 * j * lda) * 4, smem + wbase + 32 * j * GEMM_BK);
+        GLDS16(rsW, voW, (32 * j * K) * 4, smem + 2 * GEMM_BM * GEMM_BK + wbase + 32 * j * GEMM_BK);
     }
-    {
-        float* As = smem;
-        float* Ws = smem + 2 * GEMM_BM * GEMM_BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *(f32x4*)(As + sdst + 32 * j * GEMM_BK) = ra[j];
-            *(f32x4*)(Ws + sdst + 32 * j * GEMM_BK) = rw[j];
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            const int k1 = (kt + 1) * GEMM_BK;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *(const f32x4*)(gA + (size_t)(32 * j) * lda + k1);
-                rw[j] = *(const f32x4*)(gW + (size_t)(32 * j) * K + k1);
-            }
-        }
-        const float* As = smem + cur * GEMM_BM * GEMM_BK;
-        const float* Ws = smem + 2 * GEMM_BM * GEMM_BK + cur * GEMM_BN * GEMM_BK;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ch = ((2 * s + h) ^ fsw) << 2;
-            f32x4 fa[2], fb[2];
-            fa[0] = *(const f32x4*)(As + aoff[0] + ch);
-            fa[1] = *(const f32x4*)(As + aoff[1] + ch);
-            fb[0] = *(const f32x4*)(Ws + boff[0] + ch);
-            fb[1] = *(const f32x4*)(Ws + boff[1] + ch);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[0][e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][e], fb[1][e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[0][e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][e], fb[1][e], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (more) {
-            float* Ad = smem + (cur ^ 1) * GEMM_BM * GEMM_BK;
-            float* Wd = smem + 2 * GEMM_BM * GEMM_BK + (cur ^ 1) * GEMM_BN * GEMM_BK;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *(f32x4*)(Ad + sdst + 32 * j * GEMM_BK) = ra[j];
-                *(f32x4*)(Wd + sdst + 32 * j * GEMM_BK) = rw[j];
-            }
-        }
+#define GEMM_TILE_BODY(STAGE_NEXT)                                                                         \
+    {                                                                                                      \
+        const float* As = smem + cur * GEMM_BM * GEMM_BK;                                                  \
+        const float* Ws = smem + 2 * GEMM_BM * GEMM_BK + cur * GEMM_BN * GEMM_BK;                          \
+        float* Ad = smem + (cur ^ 1) * GEMM_BM * GEMM_BK + wbase;                                          \
+        float* Wd = smem + 2 * GEMM_BM * GEMM_BK + (cur ^ 1) * GEMM_BN * GEMM_BK + wbase;                  \
+        const int k1 = (kt + 1) * GEMM_BK;                                                                 \
+        if (STAGE_NEXT) {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                GLDS16(rsA, voA, (32 * j * lda + k1) * 4, Ad + 32 * j * GEMM_BK);                          \
+                GLDS16(rsW, voW, (32 * j * K + k1) * 4, Wd + 32 * j * GEMM_BK);                            \
+            }                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+        f32x4 fa[2][2], fb[2][2];                                                                          \
+        {                                                                                                  \
+            const int ch = (h ^ fsw) << 2;                                                                 \
+            fa[0][0] = *(const f32x4*)(As + aoff[0] + ch);                                                 \
+            fa[0][1] = *(const f32x4*)(As + aoff[1] + ch);                                                 \
+            fb[0][0] = *(const f32x4*)(Ws + boff[0] + ch);                                                 \
+            fb[0][1] = *(const f32x4*)(Ws + boff[1] + ch);                                                 \
+        }                                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
+            const int c = s & 1, n = c ^ 1;                                                                \
+            if (s < 3) { /* fragments of k-step s+1 are fetched a full step (16 MFMAs) ahead */            \
+                const int ch = ((2 * (s + 1) + h) ^ fsw) << 2;                                             \
+                fa[n][0] = *(const f32x4*)(As + aoff[0] + ch);                                             \
+                fa[n][1] = *(const f32x4*)(As + aoff[1] + ch);                                             \
+                fb[n][0] = *(const f32x4*)(Ws + boff[0] + ch);                                             \
+                fb[n][1] = *(const f32x4*)(Ws + boff[1] + ch);                                             \
+                __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of this step's MFMAs */      \
+            }                                                                                              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][e], fb[c][0][e], acc[0][0], 0, 0, 0); \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][e], fb[c][1][e], acc[0][1], 0, 0, 0); \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][e], fb[c][0][e], acc[1][0], 0, 0, 0); \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][e], fb[c][1][e], acc[1][1], 0, 0, 0); \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+        GEMM_TILE_BODY(true)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
-
-    // epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // last tile: nothing left to stage; epilogues that read a residual prefetch it here, under the MFMAs
     const int epi = args.epi;
     const int ldc = args.ldc;
+    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
+    f32x16 res[2][2];
+    if (has_resid) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    res[a][b][r] = P.R[(size_t)(m0 + wr * 64 + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2)) * ldc +
+                                       n0 + wc * 64 + b * 32 + i];
+    }
+    GEMM_TILE_BODY(false)
+#undef GEMM_TILE_BODY
+#undef GLDS16
+
+    // epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const float alpha = args.alpha;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -174,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) 
                 float v = acc[a][b][r] + bv;
                 if (epi == EPI_QKV) v *= scale;
                 else if (epi == EPI_BIAS_RELU) v = (v < 0.f) ? 0.f : v;
-                else if (epi == EPI_BIAS_RESID) v = v + P.R[o];
-                else if (epi == EPI_REFINE) v = P.R[o] - alpha * v;
+                else if (epi == EPI_BIAS_RESID) v = v + res[a][b][r];
+                else if (epi == EPI_REFINE) v = res[a][b][r] - alpha * v;
                 Cb[o] = v;
             }
         }

@@ -65,7 +65,7 @@ struct iefvad_handle {
     float* cls_b;
 };
 
-static const int kDefaultMicroBatch = 128;   // chunks per internal pass (32768 rows)
+static const int kDefaultMicroBatch = 256;   // chunks per internal pass (65536 rows)
 
 static int micro_batch(const iefvad_handle* h) {
     return h->cfg.micro_batch > 0 ? h->cfg.micro_batch : kDefaultMicroBatch;
