@@ -51,13 +51,26 @@ def parse():
     return p.parse_args()
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: min(affinity, cgroup quota).  The GPU box exposes all 256
+    hardware threads but caps a one-GPU job at a 16-CPU quota; oversubscribing it collapses the oracle."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("IEFVAD_CPU_THREADS", n))
+
+
 def cpu_baseline(sd, seconds):
     """The oracle (CPU restatement of the reference forward) on the host cores: B=8 chunks per call, the
     best-case batched pattern of SURVEY.md 8d, repeated for ~`seconds`."""
     import numpy as np
     from iefvad_amd import synth
     from oracle import iefvad_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cpu_share())
     cores = torch.get_num_threads()
     model = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K_STEPS, nu=8))
     img, ev = synth.make_inputs(1234, 8)

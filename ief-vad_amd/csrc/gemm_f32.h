@@ -52,6 +52,55 @@ struct GemmArgs {
 #define GEMM_BN 128
 #define GEMM_BK 32
 
+
+// Residual operand of the EPI_BIAS_RESID / EPI_REFINE epilogues, fetched in accumulator layout.
+__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& args, const GemmProblem& P, f32x16 (&res)[2][2],
+                                                       int m0, int n0, int wr, int wc, int i, int h) {
+    const int epi = args.epi, ldc = args.ldc;
+    if (epi == EPI_BIAS_RESID || epi == EPI_REFINE) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    res[a][b][r] = P.R[(size_t)(m0 + wr * 64 + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2)) * ldc +
+                                       n0 + wc * 64 + b * 32 + i];
+    }
+}
+
+// Epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, const GemmProblem& P, f32x16 (&acc)[2][2],
+                                              f32x16 (&res)[2][2], int m0, int n0, int wr, int wc, int i, int h) {
+    const int epi = args.epi, ldc = args.ldc;
+    const float alpha = args.alpha;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wc * 64 + b * 32 + i;
+        const float bv = P.bias[n];
+        float* Cb = P.C;
+        int nn = n;
+        float scale = 1.f;
+        if (epi == EPI_HEADS && n >= IEF_D) { Cb = P.C2; nn = n - IEF_D; }
+        if (epi == EPI_QKV && n < args.qcols) scale = alpha;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int mb = m0 + wr * 64 + a * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const size_t o = (size_t)m * ldc + nn;
+                float v = acc[a][b][r] + bv;
+                if (epi == EPI_QKV) v *= scale;
+                else if (epi == EPI_BIAS_RELU) v = (v < 0.f) ? 0.f : v;
+                else if (epi == EPI_BIAS_RESID) v = v + res[a][b][r];
+                else if (epi == EPI_REFINE) v = res[a][b][r] - alpha * v;
+                Cb[o] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (GEMM_BM + GEMM_BN) * GEMM_BK];   // 64 KB
     const GemmProblem& P = args.p[blockIdx.z];
@@ -163,49 +212,11 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) 
         cur ^= 1;
     }
     // last tile: nothing left to stage; epilogues that read a residual prefetch it here, under the MFMAs
-    const int epi = args.epi;
-    const int ldc = args.ldc;
-    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
     f32x16 res[2][2];
-    if (has_resid) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    res[a][b][r] = P.R[(size_t)(m0 + wr * 64 + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2)) * ldc +
-                                       n0 + wc * 64 + b * 32 + i];
-    }
+    gemm_prefetch_residual(args, P, res, m0, n0, wr, wc, i, h);
     GEMM_TILE_BODY(false)
 #undef GEMM_TILE_BODY
 #undef GLDS16
 
-    // epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const float alpha = args.alpha;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wc * 64 + b * 32 + i;
-        const float bv = P.bias[n];
-        float* Cb = P.C;
-        int nn = n;
-        float scale = 1.f;
-        if (epi == EPI_HEADS && n >= IEF_D) { Cb = P.C2; nn = n - IEF_D; }
-        if (epi == EPI_QKV && n < args.qcols) scale = alpha;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int mb = m0 + wr * 64 + a * 32 + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const size_t o = (size_t)m * ldc + nn;
-                float v = acc[a][b][r] + bv;
-                if (epi == EPI_QKV) v *= scale;
-                else if (epi == EPI_BIAS_RELU) v = (v < 0.f) ? 0.f : v;
-                else if (epi == EPI_BIAS_RESID) v = v + res[a][b][r];
-                else if (epi == EPI_REFINE) v = res[a][b][r] - alpha * v;
-                Cb[o] = v;
-            }
-        }
-    }
+    gemm_epilogue(args, P, acc, res, m0, n0, wr, wc, i, h);
 }

@@ -15,6 +15,7 @@
 #include "attention_f32.h"
 #include "common.h"
 #include "gemm_f32.h"
+#include "gemm_f32_ring.h"
 #include "rowops.h"
 
 // ------------------------------------------------------------------------------------------------

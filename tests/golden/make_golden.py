@@ -168,7 +168,30 @@ def gen_harness_case():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "ROC", roc, "AP", ap, "ano", captured["ano"])
 
 
+def gen_init_checksums():
+    """Default-initialised reference weights under torch.manual_seed(123): per-tensor sums and the first
+    four elements, so the tests can check that iefvad_amd.MMFMIL registers and initialises its
+    parameters in the reference's order (same RNG stream -> identical tensors)."""
+    sys.path.insert(0, REF)
+    from model.imf_vad import MMFMIL
+    out = {}
+    for K in (10, 0):
+        torch.manual_seed(123)
+        m = MMFMIL(14, 768, 256, 768, 8, 2, 8, 10, 10, device="cpu", args=ref_args(2, 8, K))
+        sd = m.state_dict()
+        out[f"keys_k{K}"] = np.array(list(sd.keys()))
+        out[f"sums_k{K}"] = np.array([float(v.double().sum()) for v in sd.values()])
+        out[f"head_k{K}"] = np.stack([np.resize(v.reshape(-1)[:4].double().numpy(), 4) for v in sd.values()])
+    path = os.path.join(HERE, "init_checksums.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "init":
+        gen_init_checksums()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_forward_cases()
     gen_harness_case()
+    gen_init_checksums()

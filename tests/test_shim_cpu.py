@@ -1,0 +1,53 @@
+"""The MMFMIL shim's module protocol (no GPU): state_dict layout, default initialisation and the
+attributes the reference's callers rely on."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import synth
+
+
+def make(K=10, L=2, **kw):
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5,
+                              noise_model="StudentT", nu=8)
+    return iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, **kw)
+
+
+@pytest.mark.parametrize("K", [10, 0])
+def test_seeded_default_init_equals_reference(golden_dir, K):
+    """Same parameter names, shapes, registration order AND default init as the reference: a seeded
+    construction draws the same RNG stream, so every tensor matches the reference's bit for bit."""
+    g = np.load(os.path.join(golden_dir, "init_checksums.npz"))
+    torch.manual_seed(123)
+    sd = make(K).state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[f"keys_k{K}"]]
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    head = np.stack([np.resize(v.reshape(-1)[:4].double().numpy(), 4) for v in sd.values()])
+    # fp64 sums depend on the reduction order (thread count): compare to 1e-12, the leading elements exactly
+    assert np.allclose(sums, g[f"sums_k{K}"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(head, g[f"head_k{K}"])
+
+
+def test_state_dict_roundtrip_and_counts():
+    m = make(10)
+    sd = synth.make_state_dict(5)
+    assert [k for k, _, _ in synth.state_dict_keys(2, 10)] == list(m.state_dict().keys())
+    res = m.load_state_dict(sd)            # bare state_dict, as test.py:377-378 loads it
+    assert not res.missing_keys and not res.unexpected_keys
+    assert len(sd) == 78 and sum(p.numel() for p in m.parameters()) == 23_633_665
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_attributes_used_by_callers():
+    m = make(3)
+    assert m.temporal.nu == 8                       # ucf_train.py:94-95
+    assert m.temporal.num_refinement_steps == 3 and m.temporal.lambda_ref == 0.5
+    assert m.temporal.epsilon == 1e-8               # --epsilon never reaches the model (imf_vad.py:30-38)
+    assert m.eval() is m and not m.training
+    with pytest.raises(ValueError):
+        make(1, outputs="everything")
