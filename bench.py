@@ -156,6 +156,10 @@ def main():
         launches = stage["gemm_launches"] / a.steps
         gemm_flops = GEMM_FLOPS_PER_SNIPPET * B * T                     # per step, this rank
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        traffic = None      # HBM-side bytes per GEMM launch from the committed PMC passes (same rows per launch)
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+        if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256:
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         line = {
             "metric": "snippets/sec at [B,T=256,d=768]", "value": value, "unit": "snippets/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -166,7 +170,7 @@ def main():
                        "chunks_per_gpu": B, "snippets_per_step": world * B * T,
                        "parallelism": f"video-sharded x{world}, score all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "iefvad_gemm_f32_kernel",
                          "launches_per_step": launches,
                          "avg_launch_ms": gemm_ms / launches,
