@@ -1,0 +1,95 @@
+"""BASELINE config 2 shape on the GPU: a UCF-Crime-sized synthetic test set (290 videos, ~69.5 k snippets,
+heavy-tailed lengths) scored through the product harness + HIP path, against the CPU oracle run in the
+reference's per-video pattern.  Gate: scores within the fp32 tolerance, AUC / AP / Ano-AUC equal to 4 d.p.
+Plus size-independent properties at a larger batch."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import harness, synth
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def ucf_shaped_set(seed=1, n_videos=290, total=69500):
+    lengths = synth.lognormal_lengths(seed, n_videos, total)
+    abnormal = [c for c in synth.UCF_CLASSES if c != 'Normal']
+    classes = ['Normal'] * 150 + [abnormal[i % 13] for i in range(n_videos - 150)]   # 150 normal + 140 abnormal (test.csv)
+    rng = np.random.default_rng([seed, 11])
+    order = rng.permutation(n_videos)
+    classes = [classes[i] for i in order]
+    return lengths, classes
+
+
+def items(seed, lengths, classes):
+    for i, (n, c) in enumerate(zip(lengths, classes)):
+        img, ev = synth.make_video(seed, i, int(n))
+        ci, _ = harness.process_split(img, 256)
+        ce, _ = harness.process_split(ev, 256)
+        yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), (c,), torch.tensor([int(n)])
+
+
+def gpu_model(sd, **kw):
+    args = argparse.Namespace(visual_layers=2, visual_head=8, num_refinement_steps=10, lambda_ref=0.5,
+                              noise_model="StudentT", nu=8)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, 2, 8, 10, 10, "cuda", args, **kw)
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval()
+
+
+def test_ucf_shaped_set_auc_parity():
+    seed = 1
+    lengths, classes = ucf_shaped_set(seed)
+    total = int(lengths.sum())
+    assert 60000 < total < 80000 and len(lengths) == 290
+    gt = synth.make_gt(seed, total)
+    sd = synth.make_state_dict(7)
+    model = gpu_model(sd, outputs="scores")
+    s_gpu, c_gpu, _, _ = harness.score_loader(model, items(seed, lengths, classes), 256, "cuda:0", "ucfcrime",
+                                              batch_chunks=256)
+    torch.set_num_threads(16)
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    s_cpu, c_cpu, _, _ = harness.score_loader(oracle, items(seed, lengths, classes), 256, "cpu", "ucfcrime")
+    assert c_gpu == c_cpu == classes
+    a, b = np.concatenate(s_gpu), np.concatenate(s_cpu)
+    assert a.shape == b.shape == (total,)
+    assert np.abs(a - b).max() <= H.TOL_SIGMOID
+    r_gpu = harness.evaluate_scores(s_gpu, classes, gt, "ucfcrime", verbose=False)
+    r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "ucfcrime", verbose=False)
+    for k in ("roc", "ap", "ano_auc"):
+        assert abs(r_gpu[k] - r_cpu[k]) < 1e-4, (k, r_gpu[k], r_cpu[k])     # AUC equal to 4 d.p.
+    print("config-2 shape: snippets", total, "max|dscore|", float(np.abs(a - b).max()), "AUC", r_gpu["roc"], r_cpu["roc"])
+
+
+def test_chunk_permutation_equivariance_at_scale():
+    """Chunks are independent batch rows (attention never crosses a chunk, imf_vad.py:115): permuting the
+    B=512 chunks of a call permutes the outputs, bit for bit, whatever micro-batch they land in."""
+    sd = synth.make_state_dict(8)
+    model = gpu_model(sd, outputs="scores", micro_batch=96)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    img = torch.randn(512, 256, 768, device="cuda:0", generator=g) * 0.45
+    ev = torch.randn(512, 256, 768, device="cuda:0", generator=g) * 0.45
+    perm = torch.randperm(512, device="cuda:0", generator=g)
+    with torch.no_grad():
+        a = model(img, ev, None, None, None)
+        b = model(img[perm].contiguous(), ev[perm].contiguous(), None, None, None)
+    for k in a:
+        assert torch.equal(a[k][perm], b[k]), k
+    assert bool(torch.isfinite(a["logits"]).all())
+    # zero padding after the valid rows changes the valid rows' scores (unmasked attention, Appendix C-1) ...
+    img2, ev2 = img[:2].clone(), ev[:2].clone()
+    img2[:, 100:], ev2[:, 100:] = 0, 0
+    with torch.no_grad():
+        c = model(img2, ev2, None, None, None)
+    assert not torch.equal(c["logits"][:, :100], a["logits"][:2, :100])
+    # ... and an all-zero chunk yields identical rows (every row sees the same keys)
+    z = torch.zeros(1, 256, 768, device="cuda:0")
+    with torch.no_grad():
+        d = model(z, z, None, None, None)
+    assert float((d["logits"] - d["logits"][0, 0]).abs().max()) < 1e-6
