@@ -36,6 +36,7 @@ T, D, H, L, K_STEPS = 256, 768, 8, 2, 10
 GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D) + K_STEPS * 2 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 MFMA (same table)
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
     p.add_argument("--chunks", type=int, default=8192, help="chunks [256,768] per GPU per step")
     p.add_argument("--micro-batch", type=int, default=0, help="chunks per internal pass (0 = library default)")
     p.add_argument("--outputs", default="scores", choices=["scores", "full"])
+    p.add_argument("--compute", default="f32", choices=["f32", "bf16"],
+                   help="arithmetic of the dense projections (f32 = exact-fp32 MFMA, the default parity mode)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return p.parse_args()
@@ -108,7 +111,7 @@ def main():
                                noise_model="StudentT", nu=8)
     sd = synth.make_state_dict(0, D, L, K_STEPS)
     model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
-                              micro_batch=a.micro_batch)
+                              micro_batch=a.micro_batch, compute=a.compute)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
 
@@ -158,20 +161,21 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         traffic = None      # HBM-side bytes per GEMM launch from the committed PMC passes (same rows per launch)
         tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-        if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256:
+        peak = PEAK_F32_MFMA_TFLOPS if a.compute == "f32" else PEAK_BF16_MFMA_TFLOPS
+        if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256 and a.compute == "f32":
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         line = {
             "metric": "snippets/sec at [B,T=256,d=768]", "value": value, "unit": "snippets/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.compute, "data": "synthetic",
             "config": {"workload": f"synthetic [B={B},T=256,d=768] fp32 image+event blocks per GPU resident in HBM "
                                    f"(BASELINE config 4 batch), K=10 nu=8 StudentT, seeded random weights, "
-                                   f"outputs={a.outputs}",
+                                   f"outputs={a.outputs}, projections={a.compute}",
                        "chunks_per_gpu": B, "snippets_per_step": world * B * T,
                        "parallelism": f"video-sharded x{world}, score all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "iefvad_gemm_f32_kernel",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "iefvad_gemm_f32_kernel" if a.compute == "f32" else "iefvad_gemm_bf16_kernel",
                          "launches_per_step": launches,
                          "avg_launch_ms": gemm_ms / launches,
                          "flops_per_launch": gemm_flops / launches},

@@ -19,7 +19,8 @@
 
 struct AttnArgs {
     const float* qkv[2];   // [N, 2304] per modality: q | k | v, head h at columns h*96
-    float* out[2];         // [N, 768] per modality: concat over heads
+    float* out[2];         // [N, 768] per modality: concat over heads (fp32), or
+    __bf16* outb[2];       // the same as bf16 when non-null (A operand of a bf16 out_proj)
 };
 
 #define ATT_LDK 100
@@ -29,7 +30,9 @@ __global__ __launch_bounds__(512, 2) void iefvad_attention_f32_kernel(AttnArgs a
     extern __shared__ __attribute__((aligned(16))) float kv[];   // [256][100]
     const int head = blockIdx.x, chunk = blockIdx.y, mod = blockIdx.z;
     const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
-    float* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    const size_t obase = (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    float* out = args.out[mod] ? args.out[mod] + obase : nullptr;
+    __bf16* outb = args.outb[mod] ? args.outb[mod] + obase : nullptr;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_attention_f32_kernel(AttnArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
+            if (outb) outb[(size_t)qrow * IEF_D + dt * 32 + i] = (__bf16)o[dt][r];
+            else out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
         }
 }

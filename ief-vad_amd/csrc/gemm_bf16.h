@@ -1,0 +1,200 @@
+// Dense projection GEMM, bf16 operands / fp32 accumulation (throughput mode: "bf16 projections with fp32
+// fusion state", BASELINE config 3).  Same contraction and epilogues as gemm_f32.h:
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] ),  A and W bf16, K-contiguous; bias, residual and C fp32;
+//   optionally a bf16 copy Cb of the result (the A operand of the next projection).
+//
+// v_mfma_f32_32x32x16_bf16: lane (i, h) supplies A[i][k = 8h + j], B[k = 8h + j][i'] (j = 0..7) as one
+// 16-byte fragment = one ds_read_b128; the accumulator map is the one of the fp32 kernel.
+// Tiling: 128x128 block tile, BK = 64 bf16 (128-byte rows: the LDS image, its XOR swizzle, the LDS-DMA
+// staging pattern and the fragment addressing are byte-for-byte those of the fp32 kernel), 4 waves as
+// 2x2 of 64x64, double-buffered 64 KB LDS -> 2 blocks per CU.
+// The epilogue goes through LDS: each wave parks its 64x64 fp32 tile in a private, padded LDS image and
+// re-reads it row-wise, so global stores (and the residual / bias loads) are 16 bytes per lane and whole
+// 256-byte row segments per 16 lanes instead of 4-byte (2-byte for the bf16 copy) column-strided accesses.
+#pragma once
+#include "common.h"
+#include "gemm_f32.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct GemmBProblem {
+    const bf16_t* A;     // [M, K] bf16, row stride lda (elements)
+    const bf16_t* W;     // [N, K] bf16, dense
+    const float* bias;   // [N]
+    float* C;            // [M, ldc] fp32 result, nullable
+    bf16_t* Cb;          // [M, ldc] bf16 copy of the result, nullable
+    const float* R;      // residual, fp32, same layout as C
+    float* C2;           // EPI_HEADS second output (fp32, [M, 768])
+};
+
+struct GemmBArgs {
+    GemmBProblem p[2];
+    int M, N, K;
+    int lda, ldc;
+    int epi;
+    float alpha;
+    int qcols;
+};
+
+#define GEMMB_BK 64                 // bf16 elements per k-tile (128 bytes per row)
+#define GEMMB_TILE (GEMM_BM * 32)   // floats-equivalent (4-byte units) per operand tile image: 128 rows x 128 B
+#define GEMMB_EPI_LD 68             // padded row length (floats) of the per-wave epilogue image
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * GEMMB_TILE];   // 64 KB: [A0|A1|W0|W1], reused by the epilogue
+    const GemmBProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GEMM_BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int K = args.K, lda = args.lda;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+
+    const int srow = t >> 3, sch = t & 7;
+    const int ssw = (srow >> 1) & 7;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
+                                                       (int)((GEMM_BM - 1) * lda + K) * 2, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
+                                                       (int)((GEMM_BN - 1) * K + K) * 2, 0x00020000);
+    const int voA = srow * lda * 2 + ((sch ^ ssw) << 4);
+    const int voW = srow * K * 2 + ((sch ^ ssw) << 4);
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * 32;     // 8 rows x 128 B, in 4-byte units
+#define GLDS16(rs, vo, so, lp) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+
+    const int fsw = (i >> 1) & 7;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        aoff[x] = (wr * 64 + x * 32 + i) * 32;
+        boff[x] = (wc * 64 + x * 32 + i) * 32;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / GEMMB_BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        GLDS16(rsA, voA, (32 * j * lda) * 2, smem + wbase + 32 * j * 32);
+        GLDS16(rsW, voW, (32 * j * K) * 2, smem + 2 * GEMMB_TILE + wbase + 32 * j * 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+#define GEMMB_TILE_BODY(STAGE_NEXT)                                                                          \
+    {                                                                                                        \
+        const float* As = smem + cur * GEMMB_TILE;                                                           \
+        const float* Ws = smem + 2 * GEMMB_TILE + cur * GEMMB_TILE;                                          \
+        float* Ad = smem + (cur ^ 1) * GEMMB_TILE + wbase;                                                   \
+        float* Wd = smem + 2 * GEMMB_TILE + (cur ^ 1) * GEMMB_TILE + wbase;                                  \
+        const int k1 = (kt + 1) * GEMMB_BK;                                                                  \
+        if (STAGE_NEXT) {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+                GLDS16(rsA, voA, (32 * j * lda + k1) * 2, Ad + 32 * j * 32);                                 \
+                GLDS16(rsW, voW, (32 * j * K + k1) * 2, Wd + 32 * j * 32);                                   \
+            }                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+        bf16x8 fa[2][2], fb[2][2];                                                                           \
+        {                                                                                                    \
+            const int ch = (h ^ fsw) << 2;                                                                   \
+            fa[0][0] = *(const bf16x8*)(As + aoff[0] + ch);                                                  \
+            fa[0][1] = *(const bf16x8*)(As + aoff[1] + ch);                                                  \
+            fb[0][0] = *(const bf16x8*)(Ws + boff[0] + ch);                                                  \
+            fb[0][1] = *(const bf16x8*)(Ws + boff[1] + ch);                                                  \
+        }                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                      \
+            const int c = s & 1, n = c ^ 1;                                                                  \
+            if (s < 3) {                                                                                     \
+                const int ch = ((2 * (s + 1) + h) ^ fsw) << 2;                                               \
+                fa[n][0] = *(const bf16x8*)(As + aoff[0] + ch);                                              \
+                fa[n][1] = *(const bf16x8*)(As + aoff[1] + ch);                                              \
+                fb[n][0] = *(const bf16x8*)(Ws + boff[0] + ch);                                              \
+                fb[n][1] = *(const bf16x8*)(Ws + boff[1] + ch);                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                                \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);     \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);     \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);     \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);     \
+        }                                                                                                    \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+        GEMMB_TILE_BODY(true)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------
+    // Row-wise view of the wave's 64x64 tile: lane (rq = lane >> 4, cq = lane & 15) owns columns 4 cq .. 4 cq + 3
+    // of rows rq + 4 u, u = 0..15.  The residual is fetched in that view before the last k-tile's MFMAs.
+    const int epi = args.epi, ldc = args.ldc;
+    const float alpha = args.alpha;
+    const int rq = lane >> 4, cq = lane & 15;
+    const int ncol = n0 + wc * 64 + 4 * cq;                 // first of this lane's 4 output columns
+    const int mrow = m0 + wr * 64 + rq;
+    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
+    f32x4 res[16];
+    if (has_resid) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 4 * u) * ldc + ncol);
+    }
+    GEMMB_TILE_BODY(false)
+#undef GEMMB_TILE_BODY
+#undef GLDS16
+    __syncthreads();                                        // every wave is done reading the operand images
+    float* E = smem + wave * (GEMMB_TILE);                  // 16 KB per wave; 64 x 68 floats = 17 KB would overflow:
+                                                            // the tile is parked in two 32-row halves (8.5 KB each)
+    const f32x4 bv = *(const f32x4*)(P.bias + ncol);
+    float* Cb32 = P.C;
+    bf16_t* Cb16 = P.Cb;
+    int nn = ncol;
+    f32x4 scale = {1.f, 1.f, 1.f, 1.f};
+    if (epi == EPI_HEADS && ncol >= IEF_D) { Cb32 = P.C2; nn = ncol - IEF_D; }
+    if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                           // 32-row half a of the wave tile
+        // park: accumulator (col = i, row = (r&3) + 8(r>>2) + 4h) of both 32-column blocks
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                E[((r & 3) + 8 * (r >> 2) + 4 * h) * GEMMB_EPI_LD + b * 32 + i] = acc[a][b][r];
+        // (wave-private image: LDS ops of one wave complete in order, no barrier needed)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int lr = rq + 4 * u;                      // row inside the half
+            f32x4 v = *(const f32x4*)(E + lr * GEMMB_EPI_LD + 4 * cq);
+            v = v + bv;
+            if (epi == EPI_QKV) v = v * scale;
+            else if (epi == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+            } else if (epi == EPI_BIAS_RESID) v = v + res[a * 8 + u];
+            else if (epi == EPI_REFINE) v = res[a * 8 + u] - alpha * v;
+            const size_t o = (size_t)(mrow + a * 32 + 4 * u) * ldc + nn;
+            if (Cb32) *(f32x4*)(Cb32 + o) = v;
+            if (Cb16) {
+                bf16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                *(bf16x4*)(Cb16 + o) = w;
+            }
+        }
+    }
+}

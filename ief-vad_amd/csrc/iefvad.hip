@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm_f32.h"
 #include "gemm_f32_ring.h"
+#include "gemm_bf16.h"
 #include "rowops.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -64,6 +65,13 @@ struct iefvad_handle {
     float* ref_b2[IEFVAD_MAX_STEPS];
     float* cls_w;
     float* cls_b;
+    // bf16 copies of the projection matrices (IEFVAD_COMPUTE_BF16 only)
+    bf16_t* arena_b;
+    bf16_t* in_wb[2][IEFVAD_MAX_LAYERS];
+    bf16_t* out_wb[2][IEFVAD_MAX_LAYERS];
+    bf16_t* head_wb[2];
+    bf16_t* ref_w1b[IEFVAD_MAX_STEPS];
+    bf16_t* ref_w2b[IEFVAD_MAX_STEPS];
 };
 
 static const int kDefaultMicroBatch = 256;   // chunks per internal pass (65536 rows)
@@ -90,8 +98,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         return fail("iefvad_create: num_steps %d outside 0..%d", cfg->num_steps, IEFVAD_MAX_STEPS);
     if (cfg->noise_model != IEFVAD_NOISE_GAUSSIAN && cfg->noise_model != IEFVAD_NOISE_STUDENT_T)
         return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");   // imf_vad.py:138
-    if (cfg->compute != IEFVAD_COMPUTE_F32)
-        return fail("iefvad_create: compute mode %d not built (only IEFVAD_COMPUTE_F32)", cfg->compute);
+    if (cfg->compute != IEFVAD_COMPUTE_F32 && cfg->compute != IEFVAD_COMPUTE_BF16)
+        return fail("iefvad_create: unknown compute mode %d", cfg->compute);
     if (cfg->noise_model == IEFVAD_NOISE_STUDENT_T && !(cfg->nu != 0.f))
         return fail("iefvad_create: nu must be non-zero for StudentT");
     int ndev = 0;
@@ -116,7 +124,19 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
+    if (h->arena_b) (void)hipFree(h->arena_b);
     delete h;
+}
+
+template <typename T>
+static int launch_cast(const void* in0, const void* in1, float* o0, float* o1, bf16_t* b0, bf16_t* b1, size_t n, int nsrc,
+                       hipStream_t stream) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iefvad_cast_kernel<T>, dim3((unsigned)blocks, nsrc), dim3(256), 0, stream, (const T*)in0,
+                       (const T*)in1, o0, o1, b0, b1, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, void* stream_) {
@@ -178,6 +198,28 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
     HIP_TRY(put(&h->cls_w, w->cls_w, D));
     HIP_TRY(put(&h->cls_b, w->cls_b, 1));
     if ((size_t)(p - h->arena) > h->arena_floats) return fail("iefvad_set_weights: arena overflow");
+    if (h->cfg.compute == IEFVAD_COMPUTE_BF16) {
+        // bf16 (round-to-nearest-even) copies of every projection matrix; biases, LayerNorm and the scorer stay fp32
+        const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
+        if (!h->arena_b) HIP_TRY(hipMalloc((void**)&h->arena_b, nb * sizeof(bf16_t)));
+        bf16_t* q = h->arena_b;
+        auto conv = [&](bf16_t** dst, const float* src, size_t n) -> int {
+            *dst = q;
+            q += n;
+            return launch_cast<float>(src, nullptr, nullptr, nullptr, *dst, nullptr, n, 1, stream);
+        };
+        for (int m = 0; m < 2; ++m) {
+            for (int l = 0; l < L; ++l) {
+                if (int rc = conv(&h->in_wb[m][l], h->in_w[m][l], 3 * DD)) return rc;
+                if (int rc = conv(&h->out_wb[m][l], h->out_w[m][l], DD)) return rc;
+            }
+            if (int rc = conv(&h->head_wb[m], h->head_w[m], 2 * DD)) return rc;
+        }
+        for (int k = 0; k < K; ++k) {
+            if (int rc = conv(&h->ref_w1b[k], h->ref_w1[k], DD)) return rc;
+            if (int rc = conv(&h->ref_w2b[k], h->ref_w2[k], DD)) return rc;
+        }
+    }
     h->weights_set = true;
     return 0;
 }
@@ -232,17 +274,57 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
     return 0;
 }
 
-template <typename T>
-static int launch_cast(const void* img, const void* ev, float* o0, float* o1, size_t n, hipStream_t stream) {
-    size_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(iefvad_cast_kernel<T>, dim3((unsigned)blocks, 2), dim3(256), 0, stream, (const T*)img,
-                       (const T*)ev, o0, o1, n);
+static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
+    if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMMB_BK)
+        return fail("gemm(bf16): shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
+                    GEMMB_BK);
+    dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
+    hipEvent_t e = tm.begin(stage);
+    hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), 0, stream, a);
+    tm.end(e);
+    tm.gemm_launches += 1;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 static size_t in_elem_bytes(int in_dtype) { return in_dtype == IEFVAD_IN_F32 ? 4 : 2; }
+
+// One projection in either arithmetic: fills the fp32 or the bf16 argument block from the same description.
+struct Proj {
+    const float* A32[2];      // fp32 A operand (IEFVAD_COMPUTE_F32)
+    const bf16_t* A16[2];     // bf16 A operand (IEFVAD_COMPUTE_BF16)
+    const float* W32[2];
+    const bf16_t* W16[2];
+    const float* bias[2];
+    float* C[2];              // fp32 result (nullable in bf16 mode)
+    bf16_t* Cb[2];            // bf16 copy of the result (bf16 mode only, nullable)
+    const float* R[2];
+    float* C2[2];
+    int N, ldc, epi, nz;
+    float alpha;
+    int qcols;
+};
+
+static int launch_proj(const Proj& p, bool bf16, int rows, hipStream_t stream, Timer& tm, int stage) {
+    if (!bf16) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = rows; g.N = p.N; g.K = IEF_D; g.lda = IEF_D; g.ldc = p.ldc; g.epi = p.epi; g.alpha = p.alpha; g.qcols = p.qcols;
+        for (int m = 0; m < p.nz; ++m) {
+            g.p[m].A = p.A32[m]; g.p[m].W = p.W32[m]; g.p[m].bias = p.bias[m]; g.p[m].C = p.C[m]; g.p[m].R = p.R[m];
+            g.p[m].C2 = p.C2[m];
+        }
+        return launch_gemm(g, p.nz, stream, tm, stage);
+    }
+    GemmBArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = rows; g.N = p.N; g.K = IEF_D; g.lda = IEF_D; g.ldc = p.ldc; g.epi = p.epi; g.alpha = p.alpha; g.qcols = p.qcols;
+    for (int m = 0; m < p.nz; ++m) {
+        g.p[m].A = p.A16[m]; g.p[m].W = p.W16[m]; g.p[m].bias = p.bias[m]; g.p[m].C = p.C[m]; g.p[m].Cb = p.Cb[m];
+        g.p[m].R = p.R[m]; g.p[m].C2 = p.C2[m];
+    }
+    return launch_gemm_b(g, p.nz, stream, tm, stage);
+}
 
 static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
                         size_t workspace_bytes, const iefvad_outputs* out, hipStream_t stream, Timer& tm) {
@@ -257,6 +339,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         return fail("iefvad_forward: buffers must be 16-byte aligned");
 
     const iefvad_config& c = h->cfg;
+    const bool bf = (c.compute == IEFVAD_COMPUTE_BF16);
     const int L = c.num_layers, K = c.num_steps;
     const int mb = micro_batch(h);
     const size_t D = IEF_D;
@@ -268,14 +351,17 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         const int rows = nb * IEF_T;
         const size_t R = (size_t)rows;
         const size_t row0 = (size_t)b0 * IEF_T;
+        // workspace regions, in units of R*768 floats: xin 0..2 | qkv 2..8 | att 8..10 | y 10..12 | x 12..14 | logits
         float* ws = (float*)workspace;
         float* xin[2] = {ws, ws + R * D};
         float* qkv[2] = {ws + 2 * R * D, ws + 5 * R * D};
-        float* att[2] = {ws + 8 * R * D, ws + 9 * R * D};
+        float* att[2] = {ws + 8 * R * D, ws + 9 * R * D};                       // fp32 mode: attention output
+        bf16_t* attb[2] = {(bf16_t*)(ws + 8 * R * D), (bf16_t*)(ws + 8 * R * D) + R * D};   // bf16 mode: the same region
+        bf16_t* xb[2] = {(bf16_t*)(ws + 9 * R * D), (bf16_t*)(ws + 9 * R * D) + R * D};     // holds attb | xb
         float* ybuf[2] = {ws + 10 * R * D, ws + 11 * R * D};
         float* xbuf[2] = {ws + 12 * R * D, ws + 13 * R * D};
         float* lg_scratch = ws + 14 * R * D;
-        // tail buffers alias the (dead by then) qkv region
+        // tail buffers alias the (dead by then) qkv region: mu_i lv_i mu_e lv_e z | h  (bf16 mode: hb, zb in h's slot)
         float* t0 = ws + 2 * R * D;
         float* mu_i = out->image_mu ? out->image_mu + row0 * D : t0;
         float* lv_i = out->image_logvar ? out->image_logvar + row0 * D : t0 + R * D;
@@ -283,19 +369,30 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         float* lv_e = out->event_logvar ? out->event_logvar + row0 * D : t0 + 3 * R * D;
         float* z = out->fused ? out->fused + row0 * D : t0 + 4 * R * D;
         float* hbuf = t0 + 5 * R * D;
+        bf16_t* hb = (bf16_t*)(t0 + 5 * R * D);
+        bf16_t* zb = hb + R * D;
         float* logits = out->logits ? out->logits + row0 : lg_scratch;
 
+        // 0. inputs: `.to(torch.float)` (imf_vad.py:41-42); bf16 mode also needs the bf16 operand copy
         const float* cur[2];
         const size_t in_off = row0 * D * in_elem_bytes(in_dtype);
+        const char* pi = (const char*)img + in_off;
+        const char* pe = (const char*)ev + in_off;
         if (in_dtype == IEFVAD_IN_F32) {
-            cur[0] = (const float*)((const char*)img + in_off);
-            cur[1] = (const float*)((const char*)ev + in_off);
+            cur[0] = (const float*)pi;
+            cur[1] = (const float*)pe;
+            if (bf) {
+                hipEvent_t e = tm.begin(ST_CAST);
+                int rc = launch_cast<float>(pi, pe, nullptr, nullptr, xb[0], xb[1], R * D, 2, stream);
+                tm.end(e);
+                if (rc) return rc;
+            }
         } else {
             hipEvent_t e = tm.begin(ST_CAST);
-            int rc = (in_dtype == IEFVAD_IN_F16)
-                         ? launch_cast<__half>((const char*)img + in_off, (const char*)ev + in_off, xin[0], xin[1], R * D, stream)
-                         : launch_cast<__hip_bfloat16>((const char*)img + in_off, (const char*)ev + in_off, xin[0], xin[1],
-                                                       R * D, stream);
+            bf16_t* b0p = bf ? xb[0] : nullptr;
+            bf16_t* b1p = bf ? xb[1] : nullptr;
+            int rc = (in_dtype == IEFVAD_IN_F16) ? launch_cast<__half>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, 2, stream)
+                                                 : launch_cast<__hip_bfloat16>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, 2, stream);
             tm.end(e);
             if (rc) return rc;
             cur[0] = xin[0];
@@ -304,36 +401,44 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
 
         // 1. temporal encoder (imf_vad.py:113-123): L x { in_proj, attention, out_proj + residual, LayerNorm }
         for (int l = 0; l < L; ++l) {
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.M = rows; g.N = 3 * IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = 3 * IEF_D;
-            g.epi = EPI_QKV; g.alpha = qscale; g.qcols = IEF_D;
+            Proj p;
+            memset(&p, 0, sizeof(p));
+            p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.alpha = qscale; p.qcols = IEF_D; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
-                g.p[m].A = cur[m]; g.p[m].W = h->in_w[m][l]; g.p[m].bias = h->in_b[m][l]; g.p[m].C = qkv[m];
+                p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l];
+                p.bias[m] = h->in_b[m][l]; p.C[m] = qkv[m];
             }
-            if (int rc = launch_gemm(g, 2, stream, tm, ST_QKV)) return rc;
+            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_QKV)) return rc;
 
             AttnArgs aa;
-            for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
+            memset(&aa, 0, sizeof(aa));
+            for (int m = 0; m < 2; ++m) {
+                aa.qkv[m] = qkv[m];
+                if (bf) aa.outb[m] = attb[m]; else aa.out[m] = att[m];
+            }
             hipEvent_t e = tm.begin(ST_ATT);
             hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 2), dim3(512), ATT_LDS_BYTES, stream, aa);
             tm.end(e);
             HIP_TRY(hipGetLastError());
 
-            memset(&g, 0, sizeof(g));
-            g.M = rows; g.N = IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_BIAS_RESID;
+            memset(&p, 0, sizeof(p));
+            p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
-                g.p[m].A = att[m]; g.p[m].W = h->out_w[m][l]; g.p[m].bias = h->out_b[m][l]; g.p[m].C = ybuf[m];
-                g.p[m].R = cur[m];
+                p.A32[m] = att[m]; p.A16[m] = attb[m]; p.W32[m] = h->out_w[m][l]; p.W16[m] = h->out_wb[m][l];
+                p.bias[m] = h->out_b[m][l]; p.C[m] = ybuf[m]; p.R[m] = cur[m];
             }
-            if (int rc = launch_gemm(g, 2, stream, tm, ST_OUT)) return rc;
+            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_OUT)) return rc;
 
             LnArgs la;
             memset(&la, 0, sizeof(la));
             la.nrows = rows; la.eps = 1e-5f;
             for (int m = 0; m < 2; ++m) {
-                la.x[m] = ybuf[m]; la.y[m] = xbuf[m]; la.g1[m] = h->norm_w[m][l]; la.b1[m] = h->norm_b[m][l];
+                la.x[m] = ybuf[m]; la.g1[m] = h->norm_w[m][l]; la.b1[m] = h->norm_b[m][l];
                 if (l == L - 1) { la.g2[m] = h->whiten_w[m]; la.b2[m] = h->whiten_b[m]; }   // whitening LN, :117,:123
+                // fp32 mode: x feeds both the next projection and the next residual; bf16 mode: the bf16 copy feeds the
+                // projection, the fp32 tensor is only the next layer's residual (not needed after the last layer)
+                la.y[m] = (!bf || l < L - 1) ? xbuf[m] : nullptr;
+                la.yb[m] = bf ? xb[m] : nullptr;
             }
             e = tm.begin(ST_LN);
             hipLaunchKernelGGL(iefvad_layernorm_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES, 2), dim3(256), 0, stream, la);
@@ -345,21 +450,25 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
 
         // 2. mu / logvar heads (imf_vad.py:125-128): one [768 -> 1536] projection per modality
         {
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.M = rows; g.N = 2 * IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_HEADS;
-            g.p[0].A = xbuf[0]; g.p[0].W = h->head_w[0]; g.p[0].bias = h->head_b[0]; g.p[0].C = mu_i; g.p[0].C2 = lv_i;
-            g.p[1].A = xbuf[1]; g.p[1].W = h->head_w[1]; g.p[1].bias = h->head_b[1]; g.p[1].C = mu_e; g.p[1].C2 = lv_e;
-            if (int rc = launch_gemm(g, 2, stream, tm, ST_HEAD)) return rc;
+            Proj p;
+            memset(&p, 0, sizeof(p));
+            p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
+            for (int m = 0; m < 2; ++m) {
+                p.A32[m] = xbuf[m]; p.A16[m] = xb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.bias[m] = h->head_b[m];
+            }
+            p.C[0] = mu_i; p.C2[0] = lv_i; p.C[1] = mu_e; p.C2[1] = lv_e;
+            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_HEAD)) return rc;
         }
 
-        // 3. precision weights + fusion (imf_vad.py:130-144)
+        // 3. precision weights + fusion (imf_vad.py:130-144), fp32 in both modes
         {
             FusionArgs fa;
+            memset(&fa, 0, sizeof(fa));
             fa.mu_i = mu_i; fa.lv_i = lv_i; fa.mu_e = mu_e; fa.lv_e = lv_e;
             fa.n_i = out->w_i ? out->w_i + row0 * D : nullptr;
             fa.n_e = out->w_e ? out->w_e + row0 * D : nullptr;
             fa.z = z;
+            fa.zb = bf ? zb : nullptr;
             fa.n_i_mean = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
             fa.n_e_mean = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
             fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
@@ -369,16 +478,19 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             HIP_TRY(hipGetLastError());
         }
 
-        // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149)
+        // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149); the state z stays fp32
         for (int k = 0; k < K; ++k) {
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.M = rows; g.N = IEF_D; g.K = IEF_D; g.lda = IEF_D; g.ldc = IEF_D; g.epi = EPI_BIAS_RELU;
-            g.p[0].A = z; g.p[0].W = h->ref_w1[k]; g.p[0].bias = h->ref_b1[k]; g.p[0].C = hbuf;
-            if (int rc = launch_gemm(g, 1, stream, tm, ST_REFINE)) return rc;
-            g.epi = EPI_REFINE; g.alpha = c.lambda_ref;
-            g.p[0].A = hbuf; g.p[0].W = h->ref_w2[k]; g.p[0].bias = h->ref_b2[k]; g.p[0].C = z; g.p[0].R = z;
-            if (int rc = launch_gemm(g, 1, stream, tm, ST_REFINE)) return rc;
+            Proj p;
+            memset(&p, 0, sizeof(p));
+            p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
+            p.A32[0] = z; p.A16[0] = zb; p.W32[0] = h->ref_w1[k]; p.W16[0] = h->ref_w1b[k]; p.bias[0] = h->ref_b1[k];
+            p.C[0] = bf ? nullptr : hbuf; p.Cb[0] = bf ? hb : nullptr;
+            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_REFINE)) return rc;
+            memset(&p, 0, sizeof(p));
+            p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
+            p.A32[0] = hbuf; p.A16[0] = hb; p.W32[0] = h->ref_w2[k]; p.W16[0] = h->ref_w2b[k]; p.bias[0] = h->ref_b2[k];
+            p.C[0] = z; p.R[0] = z; p.Cb[0] = (bf && k + 1 < K) ? zb : nullptr;
+            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_REFINE)) return rc;
         }
 
         // 5. scorer (imf_vad.py:150)
@@ -442,14 +554,23 @@ extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const voi
     return 0;
 }
 
-extern "C" int iefvad_gemm_bias(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                                 int32_t compute, void* stream) {
     if (!A || !W || !bias || !C) return fail("iefvad_gemm_bias: null argument");
-    if (compute != IEFVAD_COMPUTE_F32) return fail("iefvad_gemm_bias: compute mode %d not built", compute);
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS;
-    g.p[0].A = A; g.p[0].W = W; g.p[0].bias = bias; g.p[0].C = C;
     Timer tm;
-    return launch_gemm(g, 1, (hipStream_t)stream, tm, ST_QKV);
+    if (compute == IEFVAD_COMPUTE_F32) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS;
+        g.p[0].A = (const float*)A; g.p[0].W = (const float*)W; g.p[0].bias = bias; g.p[0].C = C;
+        return launch_gemm(g, 1, (hipStream_t)stream, tm, ST_QKV);
+    }
+    if (compute == IEFVAD_COMPUTE_BF16) {
+        GemmBArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS;
+        g.p[0].A = (const bf16_t*)A; g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C;
+        return launch_gemm_b(g, 1, (hipStream_t)stream, tm, ST_QKV);
+    }
+    return fail("iefvad_gemm_bias: unknown compute mode %d", compute);
 }

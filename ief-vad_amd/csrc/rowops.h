@@ -8,11 +8,20 @@
 
 #define ROW_WAVES 4   // rows per 256-thread block
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4_t to_bf16x4(f32x4 v) {
+    bf16x4_t w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (__bf16)v[e];      // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return w;
+}
+
 // ---- LayerNorm(768), eps inside the sqrt, biased variance; optionally a second LayerNorm applied to
 // the result (the "whitening" LN that directly follows the last encoder LN, imf_vad.py:116-117,122-123).
 struct LnArgs {
     const float* x[2];       // [N, 768] input (already x + attn_out from the out_proj epilogue)
-    float* y[2];             // [N, 768] output
+    float* y[2];             // [N, 768] fp32 output (nullable)
+    __bf16* yb[2];           // [N, 768] bf16 copy of the output (nullable): A operand of the next bf16 projection
     const float* g1[2];      // first LN weight/bias
     const float* b1[2];
     const float* g2[2];      // second LN (nullable: skip)
@@ -57,9 +66,16 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
     for (int j = 0; j < 3; ++j) v[j] = *(const f32x4*)(xp + 256 * j);
     ln_row(v, a.g1[mod], a.b1[mod], lane, a.eps);
     if (a.g2[mod] != nullptr) ln_row(v, a.g2[mod], a.b2[mod], lane, a.eps);
-    float* yp = a.y[mod] + (size_t)row * IEF_D + 4 * lane;
+    if (a.y[mod]) {
+        float* yp = a.y[mod] + (size_t)row * IEF_D + 4 * lane;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *(f32x4*)(yp + 256 * j) = v[j];
+        for (int j = 0; j < 3; ++j) *(f32x4*)(yp + 256 * j) = v[j];
+    }
+    if (a.yb[mod]) {
+        __bf16* yb = a.yb[mod] + (size_t)row * IEF_D + 4 * lane;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *(bf16x4_t*)(yb + 256 * j) = to_bf16x4(v[j]);
+    }
 }
 
 // ---- Student-t / Gaussian precision weights + normalised inverse-variance fusion
@@ -70,6 +86,7 @@ struct FusionArgs {
     const float* mu_i; const float* lv_i; const float* mu_e; const float* lv_e;   // [N, 768]
     float* n_i; float* n_e;     // [N, 768], nullable
     float* z;                   // [N, 768]
+    __bf16* zb;                 // [N, 768] bf16 copy of z (nullable)
     float* n_i_mean; float* n_e_mean;   // [N], nullable: mean over D (test.py:131-136)
     int nrows;
     float factor, eps;
@@ -101,6 +118,7 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
         if (a.n_i) *(f32x4*)(a.n_i + o) = ni;
         if (a.n_e) *(f32x4*)(a.n_e + o) = ne;
         *(f32x4*)(a.z + o) = z;
+        if (a.zb) *(bf16x4_t*)(a.zb + o) = to_bf16x4(z);
     }
     if (a.n_i_mean || a.n_e_mean) {
         si = wave_sum(si) * (1.0f / IEF_D);
@@ -131,16 +149,21 @@ __global__ __launch_bounds__(256) void iefvad_scorer_kernel(const float* z, cons
     if (lane == 0) logits[row] = s + b[0];
 }
 
-// ---- input cast: the reference's `.to(torch.float)` (imf_vad.py:41-42) for fp16 / bf16 feature files
+// ---- input cast: the reference's `.to(torch.float)` (imf_vad.py:41-42) for fp16 / bf16 feature files, and
+// the bf16 operand copies of the bf16-projection mode.  Two sources per launch (blockIdx.y), fp32 and/or
+// bf16 destinations (nullable).
 template <typename T>
-__global__ __launch_bounds__(256) void iefvad_cast_kernel(const T* in0, const T* in1, float* out0, float* out1, size_t n) {
+__global__ __launch_bounds__(256) void iefvad_cast_kernel(const T* in0, const T* in1, float* out0, float* out1,
+                                                          __bf16* ob0, __bf16* ob1, size_t n) {
     const T* in = blockIdx.y ? in1 : in0;
     float* out = blockIdx.y ? out1 : out0;
+    __bf16* ob = blockIdx.y ? ob1 : ob0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx * 4 < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t o = idx * 4;   // n is a multiple of 768
+        const size_t o = idx * 4;   // n is a multiple of 4
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (float)in[o + e];
-        *(f32x4*)(out + o) = v;
+        if (out) *(f32x4*)(out + o) = v;
+        if (ob) *(bf16x4_t*)(ob + o) = to_bf16x4(v);
     }
 }

@@ -112,11 +112,14 @@ class MMFMIL(nn.Module):
                    (only `logits` plus the per-row means `w_i_mean`, `w_e_mean`; nothing 768-wide
                    is written to HBM).
       micro_batch  chunks per internal pass of the library (0 = library default).
+      compute      "f32" (default): exact-fp32 MFMA projections, the parity mode;
+                   "bf16": bf16 operands / fp32 accumulation in the dense projections only; attention,
+                   LayerNorm, the fusion and the refinement state stay fp32 (BASELINE config 3).
     """
 
     def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
                  visual_layers: int, attn_window: int, prompt_prefix: int, prompt_postfix: int, device, args,
-                 *, outputs: str = "full", micro_batch: int = 0):
+                 *, outputs: str = "full", micro_batch: int = 0, compute: str = "f32"):
         super().__init__()
         self.num_class = num_class
         self.visual_length = visual_length
@@ -131,8 +134,11 @@ class MMFMIL(nn.Module):
                                      noise_model=args.noise_model, nu=args.nu)
         if outputs not in ("full", "scores"):
             raise ValueError("outputs must be 'full' or 'scores'")
+        if compute not in ("f32", "bf16"):
+            raise ValueError("compute must be 'f32' or 'bf16'")
         self.outputs = outputs
         self.micro_batch = micro_batch
+        self.compute = compute
         self._handle: Optional[C.c_void_p] = None
         self._handle_key = None
         self._weights_sig = None
@@ -164,14 +170,15 @@ class MMFMIL(nn.Module):
     def _ensure_handle(self, device: torch.device):
         t = self.temporal
         key = (device.index, t.embed_dim, self.visual_length, t.num_heads, t.num_layers, t.num_refinement_steps,
-               self._noise_code(), float(t.lambda_ref), float(t.nu), float(t.epsilon), int(self.micro_batch))
+               self._noise_code(), float(t.lambda_ref), float(t.nu), float(t.epsilon), int(self.micro_batch), self.compute)
         if self._handle is not None and key == self._handle_key:
             return
         self._release()
         lib = _lib.load_library()
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, embed_dim=t.embed_dim, seq_len=self.visual_length,
                           num_heads=t.num_heads, num_layers=t.num_layers, num_steps=t.num_refinement_steps,
-                          noise_model=self._noise_code(), compute=_lib.COMPUTE_F32, lambda_ref=float(t.lambda_ref),
+                          noise_model=self._noise_code(),
+                          compute=_lib.COMPUTE_BF16 if self.compute == "bf16" else _lib.COMPUTE_F32, lambda_ref=float(t.lambda_ref),
                           nu=float(t.nu), epsilon=float(t.epsilon), micro_batch=int(self.micro_batch))
         h = C.c_void_p()
         with torch.cuda.device(device):

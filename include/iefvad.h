@@ -141,8 +141,10 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
                          iefvad_stage_times* times);
 
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
- * kernel (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 32 == 0. */
-int iefvad_gemm_bias(const float* A, const float* W, const float* bias, float* C,
+ * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
+ * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);
+ * bias and C are fp32 in both. */
+int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C,
                      int32_t M, int32_t N, int32_t K, int32_t compute, void* stream);
 
 const char* iefvad_last_error(void);

@@ -50,7 +50,7 @@ def test_create_rejects_bad_config_without_touching_the_gpu(lib):
                 noise_model=1, compute=0, lambda_ref=0.5, nu=8.0, epsilon=1e-8, micro_batch=0)
     for bad, frag in [(dict(embed_dim=512), "D=768"), (dict(num_layers=0), "num_layers"), (dict(num_steps=65), "num_steps"),
                       (dict(noise_model=7), "Unsupported noise_model"), (dict(abi_version=9), "abi_version"),
-                      (dict(compute=1), "compute mode")]:
+                      (dict(compute=5), "compute mode")]:
         cfg = L.Config(**dict(base, **bad))
         assert lib.iefvad_create(C.byref(cfg), C.byref(h)) != 0
         assert frag in L.last_error(), (bad, L.last_error())

@@ -1,0 +1,105 @@
+"""Throughput mode (bf16 operands / fp32 accumulation in the dense projections, everything else fp32 --
+BASELINE config 3) against the golden vectors of the fp32 reference and, for AUC, against the CPU oracle.
+Tolerances are the bf16-operand noise floor measured in SURVEY.md 8c: <= 1.1e-2 on the 768-d outputs,
+<= 4.3e-3 on logits, <= 1.1e-3 on sigmoid(logit); gates sit ~3x above."""
+import argparse
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import harness, synth
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_BIG_BF16 = 4e-2
+TOL_LOGIT_BF16 = 1.5e-2
+TOL_SIGMOID_BF16 = 4e-3
+
+
+def make_model(L, K, lam, noise, nu, sd, **kw):
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=lam,
+                              noise_model=noise, nu=nu)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, compute="bf16", **kw)
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval()
+
+
+def test_bf16_gemm_kernel_matches_fp64_of_rounded_operands():
+    """The kernel must be exact up to fp32 accumulation once the operands are bf16: compare with an fp64 product
+    of the SAME bf16-rounded operands (asymmetric data catches a transposed fragment or accumulator map)."""
+    lib = iefvad_amd.lib.load_library()
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K) in [(128, 128, 64), (256, 768, 768), (512, 2304, 768)]:
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+        W = torch.randn(N, K, generator=g).to(torch.bfloat16)
+        b = torch.randn(N, generator=g)
+        dA, dW, db = A.cuda(), W.cuda(), b.cuda()
+        dC = torch.empty(M, N, device="cuda")
+        rc = lib.iefvad_gemm_bias(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), dC.data_ptr(), M, N, K, 1,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, iefvad_amd.lib.last_error()
+        torch.cuda.synchronize()
+        ref = A.double() @ W.double().t() + b.double()
+        err = (dC.cpu().double() - ref).abs().max().item()
+        assert err < 2e-4, (M, N, K, err)
+
+
+@pytest.mark.parametrize("name", H.golden_cases())
+def test_bf16_forward_within_bf16_noise_of_reference(name):
+    g, cfg, sd, img, ev = H.load_case(name)
+    model = make_model(cfg["L"], cfg["K"], cfg["lam"], cfg["noise"], cfg["nu"], sd)
+    with torch.no_grad():
+        out = model(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    errs = H.compare_outputs(out, g, TOL_BIG_BF16, TOL_LOGIT_BF16, TOL_SIGMOID_BF16)
+    print(name, errs)
+
+
+def test_bf16_scores_mode_and_microbatch_bit_identical():
+    sd = synth.make_state_dict(31, 768, 2, 3)
+    img, ev = synth.make_inputs(32, 5)
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    with torch.no_grad():
+        a = make_model(2, 3, 0.5, "StudentT", 8, sd)(ti, te, None, None, None)
+        b = make_model(2, 3, 0.5, "StudentT", 8, sd, micro_batch=2, outputs="scores")(ti, te, None, None, None)
+    assert torch.equal(a["logits"], b["logits"])
+    assert (b["w_i_mean"] - a["w_i"].mean(-1)).abs().max().item() < 1e-6
+
+
+def test_xd_shaped_set_auc_and_ap_parity_bf16():
+    """BASELINE config 3: XD-Violence-sized synthetic set (753 videos, ~145 k snippets), bf16 projections,
+    AUC and AP (XD selects by AP, xd_train.py:114) equal to 4 d.p. against the fp32 CPU oracle."""
+    seed = 2
+    lengths = synth.lognormal_lengths(seed, 753, 145000)
+    keys = harness.CLASS_KEYS['xd']
+    classes = [keys[i % len(keys)] for i in range(753)]
+    total = int(lengths.sum())
+    gt = synth.make_gt(seed, total)
+    sd = synth.make_state_dict(17)
+
+    def items():
+        for i, (n, c) in enumerate(zip(lengths, classes)):
+            img, ev = synth.make_video(seed, i, int(n))
+            ci, _ = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), (c,), torch.tensor([int(n)])
+
+    model = make_model(2, 10, 0.5, "StudentT", 8, sd, outputs="scores")
+    s_gpu, _, _, _ = harness.score_loader(model, items(), 256, "cuda:0", "xd", batch_chunks=512)
+    torch.set_num_threads(16)
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    s_cpu, _, _, _ = harness.score_loader(oracle, items(), 256, "cpu", "xd", batch_chunks=8)
+    a, b = np.concatenate(s_gpu), np.concatenate(s_cpu)
+    assert a.shape == b.shape == (total,)
+    dmax = float(np.abs(a - b).max())
+    assert dmax <= TOL_SIGMOID_BF16, dmax
+    r_gpu = harness.evaluate_scores(s_gpu, classes, gt, "xd", verbose=False, normal_keys=('normal',))
+    r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "xd", verbose=False, normal_keys=('normal',))
+    for k in ("roc", "ap", "ano_auc"):
+        assert abs(r_gpu[k] - r_cpu[k]) < 1e-4, (k, r_gpu[k], r_cpu[k])
+    print("config-3 shape: snippets", total, "max|dscore|", dmax, "AUC", r_gpu["roc"], r_cpu["roc"], "AP", r_gpu["ap"], r_cpu["ap"])
