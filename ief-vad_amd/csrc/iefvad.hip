@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "attention_f32.h"
+#include "attention_bf16.h"
 #include "common.h"
 #include "gemm_f32.h"
 #include "gemm_f32_ring.h"
@@ -355,6 +356,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         float* ws = (float*)workspace;
         float* xin[2] = {ws, ws + R * D};
         float* qkv[2] = {ws + 2 * R * D, ws + 5 * R * D};
+        bf16_t* qkvb[2] = {(bf16_t*)(ws + 2 * R * D), (bf16_t*)(ws + 2 * R * D) + 3 * R * D};   // bf16 mode: q|k|v as bf16
         float* att[2] = {ws + 8 * R * D, ws + 9 * R * D};                       // fp32 mode: attention output
         bf16_t* attb[2] = {(bf16_t*)(ws + 8 * R * D), (bf16_t*)(ws + 8 * R * D) + R * D};   // bf16 mode: the same region
         bf16_t* xb[2] = {(bf16_t*)(ws + 9 * R * D), (bf16_t*)(ws + 9 * R * D) + R * D};     // holds attb | xb
@@ -403,21 +405,27 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         for (int l = 0; l < L; ++l) {
             Proj p;
             memset(&p, 0, sizeof(p));
-            p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.alpha = qscale; p.qcols = IEF_D; p.nz = 2;
+            p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
+            // q is pre-scaled for the softmax: 1/sqrt(96) (fp32, exp) or log2(e)/sqrt(96) (bf16 mode, exp2)
+            p.alpha = bf ? qscale * 1.4426950408889634f : qscale;
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l];
-                p.bias[m] = h->in_b[m][l]; p.C[m] = qkv[m];
+                p.bias[m] = h->in_b[m][l];
+                if (bf) p.Cb[m] = qkvb[m]; else p.C[m] = qkv[m];
             }
             if (int rc = launch_proj(p, bf, rows, stream, tm, ST_QKV)) return rc;
 
-            AttnArgs aa;
-            memset(&aa, 0, sizeof(aa));
-            for (int m = 0; m < 2; ++m) {
-                aa.qkv[m] = qkv[m];
-                if (bf) aa.outb[m] = attb[m]; else aa.out[m] = att[m];
-            }
             hipEvent_t e = tm.begin(ST_ATT);
-            hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 2), dim3(512), ATT_LDS_BYTES, stream, aa);
+            if (bf) {
+                AttnBArgs ab;
+                for (int m = 0; m < 2; ++m) { ab.qkv[m] = qkvb[m]; ab.out[m] = attb[m]; }
+                hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, nb, 4), dim3(256), 0, stream, ab);
+            } else {
+                AttnArgs aa;
+                memset(&aa, 0, sizeof(aa));
+                for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
+                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 2), dim3(512), ATT_LDS_BYTES, stream, aa);
+            }
             tm.end(e);
             HIP_TRY(hipGetLastError());
 

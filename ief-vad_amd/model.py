@@ -113,8 +113,9 @@ class MMFMIL(nn.Module):
                    is written to HBM).
       micro_batch  chunks per internal pass of the library (0 = library default).
       compute      "f32" (default): exact-fp32 MFMA projections, the parity mode;
-                   "bf16": bf16 operands / fp32 accumulation in the dense projections only; attention,
-                   LayerNorm, the fusion and the refinement state stay fp32 (BASELINE config 3).
+                   "bf16": bf16 MFMA operands with fp32 accumulation in the dense projections and in the two
+                   attention products; softmax, LayerNorm, the residual stream, the fusion and the refinement
+                   state stay fp32 (BASELINE config 3).
     """
 
     def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
