@@ -5,6 +5,7 @@ multi-GPU sharding.  Counterparts of
   * `test()`                                      /root/reference/test.py:46-212,
                                                    train/ucf_test.py:16-216, train/xd_test.py:15-210
   * `compute_ano_auc`                             /root/reference/test.py:332-348
+  * `run_test` (robustness sweep)                 /root/reference/test2.py:35-123
 The model is any callable with the reference's `model(img, ev, padding_mask, text, lengths)` contract.
 """
 from __future__ import annotations
@@ -134,6 +135,37 @@ def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np
     return {"roc": roc, "ap": ap, "ano_auc": ano, "per_class": per_class}
 
 
+def device_auc_ap(scores: torch.Tensor, gt: torch.Tensor, repeat: int = 16) -> Tuple[float, float]:
+    """ROC-AUC and average precision of `np.repeat(scores, repeat)` against frame-level `gt` without leaving
+    the device and without materialising the repeat (the metric tail of test.py:158-159 costs sklearn a sort
+    of 16 x N points on the host).  Ties are handled as sklearn does: thresholds are the DISTINCT score
+    values; a snippet contributes its `repeat` frames at one threshold.
+      AUC = (sum over thresholds of trapezoids) = [sum_g P_g * (N_below_g + N_g / 2)] / (P * N)
+      AP  = sum_g (R_g - R_{g-1}) * Prec_g   with groups g in decreasing score order."""
+    s = scores.reshape(-1).to(torch.float64)
+    g = gt.reshape(-1, repeat).to(torch.float64).to(s.device)
+    assert g.shape[0] == s.shape[0], "gt must hold `repeat` frames per snippet"
+    pos = g.sum(dim=1)                        # positives among this snippet's frames
+    neg = repeat - pos
+    order = torch.argsort(s, descending=True, stable=True)
+    s, pos, neg = s[order], pos[order], neg[order]
+    new_group = torch.ones_like(s, dtype=torch.bool)
+    new_group[1:] = s[1:] != s[:-1]
+    gid = torch.cumsum(new_group.to(torch.int64), 0) - 1
+    ng = int(gid[-1].item()) + 1
+    Pg = torch.zeros(ng, dtype=torch.float64, device=s.device).index_add_(0, gid, pos)
+    Ng = torch.zeros(ng, dtype=torch.float64, device=s.device).index_add_(0, gid, neg)
+    P, N = Pg.sum(), Ng.sum()
+    tp = torch.cumsum(Pg, 0)
+    fp = torch.cumsum(Ng, 0)
+    # AUC: positives of group g beat every negative in later (lower-score) groups and tie with their own
+    neg_below = N - fp
+    auc = ((Pg * (neg_below + 0.5 * Ng)).sum() / (P * N)).item()
+    prec = tp / (tp + fp)
+    ap = ((Pg / P) * prec).sum().item()
+    return auc, ap
+
+
 # ------------------------------------------------------------------------------------------------
 # the evaluation loop
 # ------------------------------------------------------------------------------------------------
@@ -225,6 +257,97 @@ def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, 
     if attn:
         return res["roc"], res["ap"], [], classes
     return res["roc"], res["ap"]
+
+
+# ------------------------------------------------------------------------------------------------
+# robustness sweep (second inference caller): /root/reference/test2.py:16-123
+# ------------------------------------------------------------------------------------------------
+SWEEP_CFGS = {   # test2.py:29-32
+    "IMG_NOISE": {"sigma_img": [0, 0.05, 0.1, 0.2, 0.3, 0.5], "sigma_ev": [0]},
+    "EV_NOISE": {"sigma_ev": [0, 0.05, 0.1, 0.2, 0.3, 0.5], "sigma_img": [0]},
+}
+
+
+def brier_score(pred, gt):
+    return np.mean((pred - gt) ** 2)
+
+
+def kl_divergence(pred_clean, pred_noisy, eps=1e-8):
+    p, q = np.clip(pred_clean, eps, 1 - eps), np.clip(pred_noisy, eps, 1 - eps)
+    return np.mean(p * np.log(p / q) + (1 - p) * np.log((1 - p) / (1 - q)))
+
+
+def run_perturbation_test(args, model, loader, gt, device, sigma_img=0, sigma_ev=0, clean_cache: Optional[dict] = None):
+    """Counterpart of `run_test` (test2.py:35-123): per video one clean and one perturbed forward, where
+    the perturbation scales a random `int(T * sigma)` subset of TIME STEPS (dim 1, all chunks alike) of one
+    modality by 0.01 (:71-77; indices from `torch.randperm`, so seeding torch reproduces the reference's
+    draw sequence).  Returns the reference's 12-tuple.  `clean_cache` (a dict kept by the caller across
+    sweep levels) lets the clean forward, identical for every level, run once instead of 12 times."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    model.eval()
+    maxlen = args.visual_length
+    repeat = 16
+    preds_clean, preds_noisy = [], []
+    w_img_orig, w_ev_orig, w_img_all, w_ev_all = [], [], [], []
+
+    def weights(out, length):
+        wi = out['w_i'].reshape(-1, out['w_i'].shape[-1])[:length].float().cpu()
+        we = out['w_e'].reshape(-1, out['w_e'].shape[-1])[:length].float().cpu()
+        return wi, we
+
+    with torch.no_grad():
+        for vid, (visuals, events, _, length) in enumerate(loader):
+            visuals = visuals.squeeze(0)
+            events = events.squeeze(0)
+            length = int(length)
+            if length < maxlen:
+                visuals = visuals.unsqueeze(0)
+                events = events.unsqueeze(0)
+            visuals = torch.nan_to_num(visuals).to(device)       # unconditional here (test2.py:59-60)
+            events = torch.nan_to_num(events).to(device)
+
+            if clean_cache is not None and vid in clean_cache:
+                p_c, wi_c, we_c = clean_cache[vid]
+            else:
+                out_c = model(visuals, events, None, None, torch.tensor([length]))
+                p_c = torch.sigmoid(out_c['logits'].reshape(-1)[:length]).float().cpu()
+                wi_c, we_c = weights(out_c, length)
+                if clean_cache is not None:
+                    clean_cache[vid] = (p_c, wi_c, we_c)
+            w_img_orig.append(wi_c)
+            w_ev_orig.append(we_c)
+
+            v_p, e_p = visuals.clone(), events.clone()
+            if sigma_img:
+                idx = torch.randperm(v_p.shape[1])[: int(v_p.shape[1] * sigma_img)]
+                v_p[:, idx] = v_p[:, idx] * 0.01
+            if sigma_ev:
+                idx = torch.randperm(e_p.shape[1])[: int(e_p.shape[1] * sigma_ev)]
+                e_p[:, idx] = e_p[:, idx] * 0.01
+            out_n = model(v_p, e_p, None, None, torch.tensor([length]))
+            p_n = torch.sigmoid(out_n['logits'].reshape(-1)[:length]).float().cpu()
+            wi_n, we_n = weights(out_n, length)
+            preds_clean.append(p_c)
+            preds_noisy.append(p_n)
+            w_img_all.append(wi_n)
+            w_ev_all.append(we_n)
+
+    yc = torch.cat(preds_clean).numpy()
+    yn = torch.cat(preds_noisy).numpy()
+    yc_rep, yn_rep = np.repeat(yc, repeat), np.repeat(yn, repeat)
+    gt_slice = gt[: len(yn_rep)]
+    w_img_all, w_ev_all = torch.cat(w_img_all), torch.cat(w_ev_all)
+    w_img_orig, w_ev_orig = torch.cat(w_img_orig), torch.cat(w_ev_orig)
+    w_img_change = w_img_orig.mean(0) - w_img_all.mean(0)
+    w_ev_change = w_ev_orig.mean(0) - w_ev_all.mean(0)
+    w_img = np.repeat(w_img_all.mean(1).numpy(), repeat)
+    w_ev = np.repeat(w_ev_all.mean(1).numpy(), repeat)
+    brier = brier_score(yn_rep, gt_slice)
+    kl = kl_divergence(yc_rep, yn_rep)
+    auc = roc_auc_score(gt_slice, yn_rep)
+    ap = average_precision_score(gt_slice, yn_rep)
+    return (brier, kl, w_img.mean(), w_ev.mean(), auc, ap, np.mean(w_img[gt_slice == 1]), np.mean(w_ev[gt_slice == 1]),
+            np.mean(w_img[gt_slice == 0]), np.mean(w_ev[gt_slice == 0]), w_img_change, w_ev_change)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -168,6 +168,39 @@ def gen_harness_case():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "ROC", roc, "AP", ap, "ano", captured["ano"])
 
 
+SWEEP_LENGTHS = [40, 300, 17, 256, 90, 520]
+
+
+def gen_sweep_case():
+    """The robustness sweep's `run_test` (/root/reference/test2.py:35-123) on a small synthetic set, two
+    levels drawn from one torch RNG stream (seed 0): IMG_NOISE 0.2 then EV_NOISE 0.3."""
+    sys.path.insert(0, REF)
+    import test2 as ref_test2                     # /root/reference/test2.py
+    model = build_reference(11)
+    seed = 4
+    gt = synth.make_gt(seed, int(sum(SWEEP_LENGTHS)))
+
+    def loader():
+        for i, n in enumerate(SWEEP_LENGTHS):
+            img, ev = synth.make_video(seed, i, n)
+            from data.tools import process_split      # the reference's chunker
+            ci, _ = process_split(img, 256)
+            ce, _ = process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
+
+    args = argparse.Namespace(visual_length=256)
+    torch.manual_seed(0)
+    out = {}
+    for tag, kw in (("img02", dict(sigma_img=0.2, sigma_ev=0)), ("ev03", dict(sigma_img=0, sigma_ev=0.3))):
+        r = ref_test2.run_test(args, model, loader(), gt, "cpu", **kw)
+        out[tag + "_scalars"] = np.array([float(x) for x in r[:10]])
+        out[tag + "_w_img_change"] = r[10].numpy()
+        out[tag + "_w_ev_change"] = r[11].numpy()
+    path = os.path.join(HERE, "sweep_test2.npz")
+    np.savez_compressed(path, lengths=np.array(SWEEP_LENGTHS), seed=np.array(seed), wseed=np.array(11), **out)
+    print("wrote", path, out["img02_scalars"])
+
+
 def gen_init_checksums():
     """Default-initialised reference weights under torch.manual_seed(123): per-tensor sums and the first
     four elements, so the tests can check that iefvad_amd.MMFMIL registers and initialises its
@@ -191,7 +224,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         gen_init_checksums()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        gen_sweep_case()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_forward_cases()
     gen_harness_case()
     gen_init_checksums()
+    gen_sweep_case()

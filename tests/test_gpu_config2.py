@@ -93,3 +93,41 @@ def test_chunk_permutation_equivariance_at_scale():
     with torch.no_grad():
         d = model(z, z, None, None, None)
     assert float((d["logits"] - d["logits"][0, 0]).abs().max()) < 1e-6
+
+
+def test_device_metric_tail_matches_sklearn_on_gpu():
+    """AUC / AP computed on the device from the gathered scores equal sklearn's on the x16 repeat."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    rng = np.random.default_rng(9)
+    n = 69510
+    s = rng.random(n).astype(np.float32)
+    s[::7] = s[1::7][: len(s[::7])]                       # ties
+    gt = (rng.random(16 * n) < 0.2).astype(np.float64)
+    auc, ap = harness.device_auc_ap(torch.from_numpy(s).cuda(), torch.from_numpy(gt).cuda())
+    assert abs(auc - roc_auc_score(gt, np.repeat(s, 16))) < 1e-10
+    assert abs(ap - average_precision_score(gt, np.repeat(s, 16))) < 1e-10
+
+
+def test_perturbation_sweep_on_gpu_matches_reference_capture(golden_dir):
+    """The robustness sweep (test2.py:35-123) through the HIP path vs the reference's own run_test capture."""
+    import os
+    g = np.load(os.path.join(golden_dir, "sweep_test2.npz"))
+    lengths, seed = [int(v) for v in g["lengths"]], int(g["seed"])
+    gt = synth.make_gt(seed, sum(lengths))
+    model = gpu_model(synth.make_state_dict(int(g["wseed"])))
+
+    def loader():
+        for i, n in enumerate(lengths):
+            img, ev = synth.make_video(seed, i, n)
+            ci, _ = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
+
+    args = argparse.Namespace(visual_length=256)
+    torch.manual_seed(0)
+    cache = {}
+    for tag, kw in (("img02", dict(sigma_img=0.2, sigma_ev=0)), ("ev03", dict(sigma_img=0, sigma_ev=0.3))):
+        r = harness.run_perturbation_test(args, model, loader(), gt, "cuda:0", clean_cache=cache, **kw)
+        assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), tag
+        assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
+        assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6

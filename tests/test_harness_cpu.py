@@ -106,3 +106,43 @@ def test_partition_by_snippets_is_contiguous_and_balanced():
         loads = [int(lengths[a:b].sum()) for a, b in parts]
         assert sum(loads) == int(lengths.sum())
         assert max(loads) <= lengths.sum() / world + lengths.max()
+
+
+def test_device_auc_ap_matches_sklearn_including_ties():
+    """harness.device_auc_ap (sort-based, no x16 materialisation) vs the sklearn calls of test.py:158-159."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    rng = np.random.default_rng(3)
+    for n, quant in [(500, None), (2000, 64), (37, 4)]:
+        s = rng.random(n).astype(np.float32)
+        if quant:
+            s = np.round(s * quant) / quant              # heavy ties
+        gt = (rng.random(16 * n) < 0.2 + 0.5 * np.repeat(s, 16)).astype(np.float64)
+        auc, ap = harness.device_auc_ap(torch.from_numpy(s), torch.from_numpy(gt))
+        assert abs(auc - roc_auc_score(gt, np.repeat(s, 16))) < 1e-12
+        assert abs(ap - average_precision_score(gt, np.repeat(s, 16))) < 1e-12
+
+
+def test_perturbation_sweep_reproduces_reference_run_test(golden_dir):
+    """harness.run_perturbation_test driven by the oracle vs the capture of test2.run_test (same torch RNG
+    stream -> same perturbed time steps)."""
+    g = np.load(os.path.join(golden_dir, "sweep_test2.npz"))
+    lengths, seed = [int(v) for v in g["lengths"]], int(g["seed"])
+    gt = synth.make_gt(seed, sum(lengths))
+    model = orc.OracleMMFMIL(synth.make_state_dict(int(g["wseed"])), orc.OracleConfig())
+
+    def loader():
+        for i, n in enumerate(lengths):
+            img, ev = synth.make_video(seed, i, n)
+            ci, _ = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
+
+    args = argparse.Namespace(visual_length=256)
+    torch.manual_seed(0)
+    cache = {}
+    for tag, kw in (("img02", dict(sigma_img=0.2, sigma_ev=0)), ("ev03", dict(sigma_img=0, sigma_ev=0.3))):
+        r = harness.run_perturbation_test(args, model, loader(), gt, "cpu", clean_cache=cache, **kw)
+        assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), tag
+        assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
+        assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
+    assert len(cache) == len(lengths)      # the clean forwards ran once, not once per level
