@@ -43,7 +43,7 @@ struct GemmBArgs {
 #define GEMMB_TILE (GEMM_BM * 32)   // floats-equivalent (4-byte units) per operand tile image: 128 rows x 128 B
 #define GEMMB_EPI_LD 68             // padded row length (floats) of the per-wave epilogue image
 
-__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[4 * GEMMB_TILE];   // 64 KB: [A0|A1|W0|W1], reused by the epilogue
     const GemmBProblem& P = args.p[blockIdx.z];
     const int ntn = args.N / GEMM_BN;
@@ -194,6 +194,166 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
                 *(bf16x4*)(Cb16 + o) = w;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// v2: 128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (8 accumulators), BK = 32 bf16 (64-byte rows), 3-slot
+// LDS ring (3 x 24 KB = 72 KB -> 2 blocks per CU) filled by LDS-DMA two k-tiles ahead with a COUNTED
+// s_waitcnt vmcnt(6): the k-tile of this GEMM is only 16 MFMAs (512 cycles) per wave, shorter than an L2 round
+// trip, so a one-tile-ahead double buffer (v1) exposes the DMA latency every tile; two tiles of distance
+// (>= 2048 cycles with two waves per SIMD) covers it.  The 64 x 128 wave tile needs 6 fragment reads per 16
+// MFMAs (v1: 8) and 25 % fewer staged bytes per FLOP.  LDS image per slot: [384 rows][64 B] (A rows then W
+// rows), 16-byte chunk index XOR (row>>2)&3 (conflict-free ds_read_b128).  Same k order as v1: bit-identical.
+// ------------------------------------------------------------------------------------------------------------
+#define GB2_BM 128
+#define GB2_BN 256
+#define GB2_BK 32                                   // bf16 elements per k-tile
+#define GB2_SLOT ((GB2_BM + GB2_BN) * 16)           // 4-byte units per ring slot (384 rows x 64 B)
+#define GB2_STAGES 3
+#define GB2_EPI_LD 132                              // padded row (floats) of the per-wave epilogue image (32 x 128)
+#define GB2_LDS_BYTES (GB2_STAGES * GB2_SLOT * 4)   // 73,728 B
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmBProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GB2_BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GB2_BM, n0 = tn * GB2_BN;
+    const int K = args.K, lda = args.lda;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+
+    // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3
+    const int srow = t >> 2, sch = t & 3;
+    const int ssw = (srow >> 2) & 3;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
+                                                       (int)((GB2_BM - 1) * lda + K) * 2, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
+                                                       (int)((GB2_BN - 1) * K + K) * 2, 0x00020000);
+    const int voA = srow * lda * 2 + ((sch ^ ssw) << 4);
+    const int voW = srow * K * 2 + ((sch ^ ssw) << 4);
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 16 * 16;    // this wave's 16 rows x 64 B, 4-byte units
+#define GLDS16(rs, vo, so, lp) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+#define GB2_STAGE(tile, slotbase)                                                                     \
+    {                                                                                                 \
+        float* Ad = smem + (slotbase) + wbase;                                                        \
+        float* Wd = Ad + GB2_BM * 16;                                                                 \
+        const int kk = (tile) * GB2_BK;                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) GLDS16(rsA, voA, (64 * j * lda + kk) * 2, Ad + 64 * j * 16); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(rsW, voW, (64 * j * K + kk) * 2, Wd + 64 * j * 16);   \
+    }
+
+    const int fsw = (i >> 2) & 3;
+    int aoff[2], boff[4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) aoff[x] = (wr * 64 + x * 32 + i) * 16;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) boff[x] = GB2_BM * 16 + (wc * 128 + x * 32 + i) * 16;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+#define GB2_COMPUTE(slotbase)                                                                               \
+    {                                                                                                       \
+        const float* S = smem + (slotbase);                                                                 \
+        bf16x8 fa[2][2], fb[2][4];                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
+            const int ch = ((2 * s + h) ^ fsw) << 2;                                                        \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) fa[s][x] = *(const bf16x8*)(S + aoff[x] + ch);    \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) fb[s][x] = *(const bf16x8*)(S + boff[x] + ch);    \
+        }                                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                   \
+                _Pragma("unroll") for (int b = 0; b < 4; ++b)                                               \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][a], fb[s][b], acc[a][b], 0, 0, 0); \
+    }
+
+    const int nk = K / GB2_BK;       // >= 2
+    int s0 = 0, s1 = GB2_SLOT, s2 = 2 * GB2_SLOT;     // slot of tile kt, kt+1, kt+2 (float offsets), rotated each tile
+    GB2_STAGE(0, s0)
+    GB2_STAGE(1, s1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        GB2_STAGE(kt + 2, s2)                         // s2 held tile kt-1: every wave passed the barrier after reading it
+        __builtin_amdgcn_sched_barrier(0);
+        GB2_COMPUTE(s0)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own DMAs of tile kt+1 landed; tile kt+2's six stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
+    }
+    GB2_COMPUTE(s0)                                   // tile nk-2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GB2_COMPUTE(s1)                                   // tile nk-1
+#undef GB2_COMPUTE
+#undef GB2_STAGE
+#undef GLDS16
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // every wave is done with the ring: reuse it for the epilogue
+
+    // ---- epilogue through LDS: the wave parks 32 rows x 128 columns at a time and re-reads them row-wise;
+    // lane (rq = lane >> 5, cq = lane & 31) owns columns 4 cq .. 4 cq + 3 of rows rq + 2 u, u = 0..15.
+    const int epi = args.epi, ldc = args.ldc;
+    const float alpha = args.alpha;
+    const int rq = lane >> 5, cq = lane & 31;
+    const int ncol = n0 + wc * 128 + 4 * cq;
+    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
+    float* E = smem + wave * (32 * GB2_EPI_LD);       // 16.9 KB per wave
+    const f32x4 bv = *(const f32x4*)(P.bias + ncol);
+    float* C32 = P.C;
+    bf16_t* C16 = P.Cb;
+    int nn = ncol;
+    f32x4 scale = {1.f, 1.f, 1.f, 1.f};
+    if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
+    if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mrow = m0 + wr * 64 + a * 32 + rq;
+        f32x4 res[16];
+        if (has_resid) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            f32x4 v = *(const f32x4*)(E + (rq + 2 * u) * GB2_EPI_LD + 4 * cq);
+            v = v + bv;
+            if (epi == EPI_QKV) v = v * scale;
+            else if (epi == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+            } else if (epi == EPI_BIAS_RESID) v = v + res[u];
+            else if (epi == EPI_REFINE) v = res[u] - alpha * v;
+            const size_t o = (size_t)(mrow + 2 * u) * ldc + nn;
+            if (C32) *(f32x4*)(C32 + o) = v;
+            if (C16) {
+                bf16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                *(bf16x4*)(C16 + o) = w;
             }
         }
     }

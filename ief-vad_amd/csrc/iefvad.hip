@@ -114,6 +114,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_f32_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GB2_LDS_BYTES);
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -276,12 +279,19 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
 }
 
 static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
-    if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMMB_BK)
-        return fail("gemm(bf16): shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
-                    GEMMB_BK);
-    dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
-    hipEvent_t e = tm.begin(stage);
-    hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), 0, stream, a);
+    hipEvent_t e;
+    if (a.N % GB2_BN == 0 && a.M % GB2_BM == 0 && a.K % GB2_BK == 0 && a.K >= 2 * GB2_BK) {
+        dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
+        e = tm.begin(stage);
+        hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, a);
+    } else {
+        if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMMB_BK)
+            return fail("gemm(bf16): shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM,
+                        GEMM_BN, GEMMB_BK);
+        dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
+        e = tm.begin(stage);
+        hipLaunchKernelGGL(iefvad_gemm_bf16_v1_kernel, grid, dim3(256), 0, stream, a);
+    }
     tm.end(e);
     tm.gemm_launches += 1;
     HIP_TRY(hipGetLastError());
