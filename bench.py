@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--outputs", default="scores", choices=["scores", "full"])
     p.add_argument("--compute", default="f32", choices=["f32", "bf16"],
                    help="arithmetic of the dense projections (f32 = exact-fp32 MFMA, the default parity mode)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl (= RCCL over xGMI) for real multi-GPU runs; gloo only to rehearse N>1 on a one-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return p.parse_args()
@@ -99,10 +101,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % max(ndev, 1)   # rehearsal: ranks share GPUs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     import iefvad_amd
     from iefvad_amd import synth
@@ -130,7 +137,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
         scores = out["logits"].reshape(-1)
         if world > 1:
-            scores = gather_scores(scores)
+            scores = gather_scores(scores if a.dist_backend == "nccl" else scores.cpu())
         return scores
 
     for _ in range(a.warmup):
@@ -147,7 +154,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if a.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert scores.numel() == world * B * T and bool(torch.isfinite(scores).all())

@@ -1,0 +1,78 @@
+// Stand-alone timing harness for the bf16 projection GEMM kernels (not part of the product library).
+// hipcc --offload-arch=gfx950 -O3 -o gemm_tune_bf16 gemm_tune_bf16.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../ief-vad_amd/csrc/gemm_bf16.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+struct Variant { const char* name; int kind; int epi; int nz; bool c32, c16; };
+
+static float time_variant(const Variant& v, GemmBArgs g, int iters) {
+    g.epi = v.epi;
+    if (v.epi == EPI_REFINE) g.alpha = 0.5f;
+    for (int m = 0; m < 2; ++m) { if (!v.c32) g.p[m].C = nullptr; if (!v.c16) g.p[m].Cb = nullptr; }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < iters; ++it) {
+        if (v.kind == 2) {
+            dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        } else {
+            dim3 grid((g.M / GEMM_BM) * (g.N / GEMM_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_v1_kernel, grid, dim3(256), 0, 0, g);
+        }
+    }
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 65536, K = 768;
+    const int iters = argc > 2 ? atoi(argv[2]) : 100, rounds = 5;
+    const int Ns[2] = {768, 2304};
+    bf16_t *A, *W, *Cb; float *bias, *C;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)2304 * K * 2)); CK(hipMalloc(&bias, 2304 * 4));
+    CK(hipMalloc(&C, (size_t)M * 2304 * 4)); CK(hipMalloc(&Cb, (size_t)M * 2304 * 2));
+    std::vector<unsigned short> h((size_t)M * K);
+    srand(1);
+    for (auto& v : h) { float f = (rand() / (float)RAND_MAX) * 2.f - 1.f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+    CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), (size_t)2304 * K * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, 2304 * 4)); CK(hipMemset(C, 0, (size_t)M * 2304 * 4));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
+    const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"v2 bias  C32", 2, EPI_BIAS, 1, true, false},
+                          {"v2 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"v2 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
+                          {"v2 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"v2 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
+                          {"v2 bias  C32 z=2", 2, EPI_BIAS, 2, true, false}, {"v2 none (no stores)", 2, EPI_BIAS, 1, false, false}};
+    const int nv = sizeof(vs) / sizeof(vs[0]);
+    for (int ni = 0; ni < 2; ++ni) {
+        GemmBArgs g; memset(&g, 0, sizeof(g));
+        g.M = M; g.N = Ns[ni]; g.K = K; g.lda = K; g.ldc = Ns[ni];
+        g.p[0].A = A; g.p[0].W = W; g.p[0].bias = bias; g.p[0].C = C; g.p[0].Cb = Cb; g.p[0].R = C; g.p[1] = g.p[0];
+        {   // v1 vs v2 bit-compare
+            std::vector<float> c1((size_t)M * g.N), c2((size_t)M * g.N);
+            time_variant(vs[0], g, 1); CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemset(C, 0, c1.size() * 4));
+            time_variant(vs[1], g, 1); CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t q = 0; q < c1.size(); ++q) bad += (c1[q] != c2[q]);
+            printf("N=%d: v2 vs v1: %zu mismatching elements of %zu\n", g.N, bad, c1.size());
+        }
+        std::vector<std::vector<float>> t(nv);
+        for (int r = 0; r < rounds; ++r)
+            for (int v = 0; v < nv; ++v) t[v].push_back(time_variant(vs[v], g, iters));
+        for (int v = 0; v < nv; ++v) {
+            std::sort(t[v].begin(), t[v].end());
+            const double fl = 2.0 * M * g.N * K * vs[v].nz;
+            printf("  %-22s N=%-5d median %.3f ms %7.1f TF   best %7.1f   worst %7.1f\n", vs[v].name, g.N, t[v][rounds / 2],
+                   fl / t[v][rounds / 2] * 1e-9, fl / t[v][0] * 1e-9, fl / t[v][rounds - 1] * 1e-9);
+        }
+    }
+    return 0;
+}
