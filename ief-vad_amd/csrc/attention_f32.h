@@ -5,15 +5,13 @@
 // ALL 256 keys -- padding_mask is accepted and ignored by the reference (imf_vad.py:40-44), so zero
 // padded rows are attended to, and this kernel does the same.
 //
-// One workgroup = one (head, chunk, modality); 8 waves x 32 query rows.  Q arrives pre-scaled by
-// 1/sqrt(96) from the in_proj epilogue.  The kernel computes the TRANSPOSED score tile
+// Q arrives pre-scaled by 1/sqrt(96) from the in_proj epilogue.  The kernel computes the TRANSPOSED score tile
 // S^T = K Q^T, so that in the 32x32 accumulator the lane index is the query and the 16 registers
 // are keys: the whole softmax row of a query lives in one lane pair (lanes q and q+32), needs no
 // LDS, and the probabilities are already laid out as the A operand of the P V product
 // (A[i = query][k = key], lane (i, h) supplying key (r&3) + 8(r>>2) + 4h of accumulator register r).
-// K and V are staged through one 100 KB LDS image [256][100 floats] (row padded 96 -> 100 so the
-// ds_read_b128 operand fetches are bank-conflict free); K is read as MFMA A operand, then the same
-// image is refilled with V, read as B operand with ds_read_b32.
+// K and V tiles are staged in LDS as [64][100 floats] (row padded 96 -> 100 so the ds_read_b128 operand
+// fetches are bank-conflict free); K is read as MFMA A operand, V as B operand with ds_read_b32.
 #pragma once
 #include "common.h"
 
@@ -24,11 +22,17 @@ struct AttnArgs {
 };
 
 #define ATT_LDK 100
-#define ATT_LDS_BYTES (IEF_T * ATT_LDK * 4)
+#define ATT_TK 64                                   // keys per staged tile
+#define ATT_TILE (ATT_TK * ATT_LDK)                 // floats per LDS tile image (25.6 KB)
 
-__global__ __launch_bounds__(512, 2) void iefvad_attention_f32_kernel(AttnArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float kv[];   // [256][100]
-    const int head = blockIdx.x, chunk = blockIdx.y, mod = blockIdx.z;
+// One workgroup = (head, chunk, modality, query half): 4 waves x 32 queries.  K then V stream through a
+// double-buffered LDS tile of 64 keys ([64][100 floats], 2 x 25.6 KB): while the waves run the 96 MFMAs of
+// tile i, the global loads of tile i+1 are in flight into registers, and they are written to the other LDS
+// buffer after the MFMAs (issue-early / write-late staging).  51 KB of LDS and <= 256 VGPRs let two workgroups
+// share a CU, so one workgroup's softmax and barriers hide under the other's matrix work.
+__global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs args) {
+    __shared__ __attribute__((aligned(16))) float kv[2 * ATT_TILE];
+    const int head = blockIdx.x, chunk = blockIdx.y, mod = blockIdx.z >> 1, qhalf = blockIdx.z & 1;
     const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
     const size_t obase = (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
     float* out = args.out[mod] ? args.out[mod] + obase : nullptr;
@@ -37,95 +41,116 @@ __global__ __launch_bounds__(512, 2) void iefvad_attention_f32_kernel(AttnArgs a
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int i = lane & 31, h = lane >> 5;
+    const int q0 = qhalf * 128 + wave * 32;
 
-    // Q fragment: lane (i, h) holds Q[wave*32 + i][8s + 4h .. +3], s = 0..11 (B operand of K Q^T)
+    // Q fragment: lane (i, h) holds Q[q0 + i][8s + 4h .. +3], s = 0..11 (B operand of K Q^T)
     f32x4 q[12];
     {
-        const float* qp = qkv + (size_t)(wave * 32 + i) * (3 * IEF_D) + 4 * h;
+        const float* qp = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 4 * h;
 #pragma unroll
         for (int s = 0; s < 12; ++s) q[s] = *(const f32x4*)(qp + 8 * s);
     }
-    // stage K: 256 rows x 24 chunks of 16 B
+    // staging map: thread t moves chunks c = t + 256 j (j = 0..5) of a 64-row x 24-chunk tile
+    int srow[6], sch[6];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const int c = t + 512 * j;
-        const int row = c / 24, ch = c - row * 24;
-        *(f32x4*)(kv + row * ATT_LDK + ch * 4) = *(const f32x4*)(qkv + (size_t)row * (3 * IEF_D) + IEF_D + ch * 4);
+    for (int j = 0; j < 6; ++j) {
+        const int c = t + 256 * j;
+        srow[j] = c / 24;
+        sch[j] = c - srow[j] * 24;
     }
+    f32x4 stg[6];
+    // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
+#define ATT_LOAD(ti)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
+        stg[j] = *(const f32x4*)(qkv + (size_t)(((ti) & 3) * ATT_TK + srow[j]) * (3 * IEF_D) +                \
+                                 ((ti) < 4 ? IEF_D : 2 * IEF_D) + sch[j] * 4);
+#define ATT_WRITE(buf)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
+        *(f32x4*)(kv + (buf) * ATT_TILE + srow[j] * ATT_LDK + sch[j] * 4) = stg[j];
+
+    ATT_LOAD(0)
+    ATT_WRITE(0)
     __syncthreads();
 
-    // S^T[key][query] = sum_d K[key][d] Q[query][d]
     f32x16 st[8];
+    f32x16 o[3];
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-        const float* kp = kv + (kt * 32 + i) * ATT_LDK + 4 * h;
-#pragma unroll
-        for (int s = 0; s < 12; ++s) {
-            const f32x4 ka = *(const f32x4*)(kp + 8 * s);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], q[s][e], st[kt], 0, 0, 0);
-        }
-    }
-
-    // softmax over the 256 keys of query (wave*32 + i): 128 values in this lane, 128 in lane i+32
-    float mx = st[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = expf(st[kt][r] - mx);
-            st[kt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
-
-    __syncthreads();   // every wave is done reading K
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const int c = t + 512 * j;
-        const int row = c / 24, ch = c - row * 24;
-        *(f32x4*)(kv + row * ATT_LDK + ch * 4) = *(const f32x4*)(qkv + (size_t)row * (3 * IEF_D) + 2 * IEF_D + ch * 4);
-    }
-    __syncthreads();
-
-    // O[query][d] = sum_key P[query][key] V[key][d]
-    f32x16 o[3];
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int ti = 0; ti < 8; ++ti) {
+        if (ti + 1 < 8) { ATT_LOAD(ti + 1) }
+        const float* T = kv + (ti & 1) * ATT_TILE;
+        if (ti < 4) {
+            // S^T[key][query] = sum_d K[key][d] Q[query][d] for the two 32-key sub-tiles of this tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float* vp = kv + key * ATT_LDK + i;
-            const float pa = st[kt][r];
+            for (int u = 0; u < 2; ++u) {
+                const float* kp = T + (u * 32 + i) * ATT_LDK + 4 * h;
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, vp[dt * 32], o[dt], 0, 0, 0);
+                for (int s = 0; s < 12; ++s) {
+                    const f32x4 ka = *(const f32x4*)(kp + 8 * s);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        st[2 * ti + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], q[s][e], st[2 * ti + u], 0, 0, 0);
+                }
+            }
+            if (ti == 3) {
+                // softmax over the 256 keys of query q0 + i: 128 values in this lane, 128 in lane i + 32
+                float mx = st[0][0];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = expf(st[kt][r] - mx);
+                        st[kt][r] = p;
+                        sum += p;
+                    }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
+            }
+        } else {
+            // O[query][d] += sum over this tile's 64 keys of P[query][key] V[key][d]
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float* vp = T + key * ATT_LDK + i;
+                    const float pa = st[2 * (ti - 4) + u][r];
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, vp[dt * 32], o[dt], 0, 0, 0);
+                }
+        }
+        if (ti + 1 < 8) {
+            ATT_WRITE((ti + 1) & 1)     // the other buffer: its previous tile (ti - 1) was released by the last barrier
+            __syncthreads();
         }
     }
+#undef ATT_LOAD
+#undef ATT_WRITE
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qrow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (outb) outb[(size_t)qrow * IEF_D + dt * 32 + i] = (__bf16)o[dt][r];
             else out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
         }

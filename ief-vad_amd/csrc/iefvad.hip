@@ -112,9 +112,6 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     h->cfg = *cfg;
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)iefvad_attention_f32_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e != hipSuccess) {
@@ -434,7 +431,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
                 AttnArgs aa;
                 memset(&aa, 0, sizeof(aa));
                 for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
-                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 2), dim3(512), ATT_LDS_BYTES, stream, aa);
+                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 4), dim3(256), 0, stream, aa);
             }
             tm.end(e);
             HIP_TRY(hipGetLastError());
