@@ -57,16 +57,8 @@ def parse():
 
 
 def host_cpu_share():
-    """CPUs this process may actually use: min(affinity, cgroup quota).  The GPU box exposes all 256
-    hardware threads but caps a one-GPU job at a 16-CPU quota; oversubscribing it collapses the oracle."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return int(os.environ.get("IEFVAD_CPU_THREADS", n))
+    from iefvad_amd.harness import host_cpu_share as f
+    return f()
 
 
 def cpu_baseline(sd, seconds):

@@ -30,6 +30,21 @@ CLASS_KEYS = {
 EVENT_DIR = {'ucfcrime': 'event_thr_10', 'xd': 'event_thr_10', 'msad': 'event_thr_10', 'shang': 'event'}
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: min(affinity, cgroup quota).  A GPU box can expose hundreds of
+    hardware threads while a one-GPU job is capped at a small quota; a torch intra-op pool sized to
+    os.cpu_count() then oversubscribes it and every small host-side tensor op crawls."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("IEFVAD_CPU_THREADS", n))
+
+
 # ------------------------------------------------------------------------------------------------
 # chunker + dataset
 # ------------------------------------------------------------------------------------------------
@@ -239,6 +254,136 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
                 flush()
         flush()
     return scores, classes, wi_means, we_means
+
+
+class FeatureFilePipeline:
+    """Streaming front end for real feature files: worker threads read the image / event
+    `.npy` pairs (numpy releases the GIL while reading) and chunk them with `process_split`; the consumer
+    packs the chunks of consecutive videos into pinned host staging buffers and issues the H2D copies on
+    a side stream, so file I/O, PCIe and the forward of the previous batch overlap.  Order is preserved.
+    Semantics match the reference loader + test() prologue: dtype preserved from disk (dataset.py:37-38,
+    49-50), conditional nan_to_num (test.py:90-95), the all-zero trailing chunk of a len % 256 == 0 video is
+    dropped (its rows are sliced away by test.py:121)."""
+
+    def __init__(self, paths: Sequence[str], labels: Sequence[str], clip_dim: int, event_dir: str, device,
+                 batch_chunks: int = 256, workers: int = 8, prefetch: int = 32):
+        self.paths, self.labels = list(paths), list(labels)
+        self.clip_dim, self.event_dir, self.device = clip_dim, event_dir, torch.device(device)
+        self.batch_chunks, self.workers, self.prefetch = batch_chunks, workers, prefetch
+
+    def _load(self, idx):
+        p = self.paths[idx]
+        img = np.load(p)
+        ev = np.load(p.replace('rgb', self.event_dir))
+        n = int(img.shape[0])
+        if np.isnan(img).any():
+            img = np.nan_to_num(img, nan=0.0)
+        if np.isnan(ev).any():
+            ev = np.nan_to_num(ev, nan=0.0)
+        return idx, img, ev, n
+
+    def batches(self):
+        """Yields (img [B,T,D] device tensor, ev, [(video index, n snippets, n chunks), ...])."""
+        from concurrent.futures import ThreadPoolExecutor
+        T = self.clip_dim
+        copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        pin = self.device.type == 'cuda'
+        with ThreadPoolExecutor(self.workers) as pool:
+            futs, nxt = [], 0
+
+            def top_up():
+                nonlocal nxt
+                while nxt < len(self.paths) and len(futs) < self.prefetch:
+                    futs.append(pool.submit(self._load, nxt))
+                    nxt += 1
+
+            top_up()
+            pend, pend_chunks = [], 0
+
+            def emit():
+                nonlocal pend, pend_chunks
+                dt = np.float32 if len({a[1].dtype for a in pend}) > 1 else pend[0][1].dtype
+                D = pend[0][1].shape[1]
+                tdt = torch.from_numpy(np.zeros(0, dt)).dtype
+                hi = torch.zeros(pend_chunks, T, D, dtype=tdt, pin_memory=pin)
+                he = torch.zeros(pend_chunks, T, D, dtype=tdt, pin_memory=pin)
+                meta, off = [], 0
+                for idx, img, ev, n in pend:
+                    nch = n // T + (1 if n % T else 0) if n >= T else 1
+                    hi[off:off + nch].reshape(-1, D)[:n] = torch.from_numpy(img.astype(dt, copy=False))
+                    he[off:off + nch].reshape(-1, D)[:n] = torch.from_numpy(ev.astype(dt, copy=False))
+                    meta.append((idx, n, nch))
+                    off += nch
+                if copy_stream is not None:
+                    with torch.cuda.stream(copy_stream):
+                        di = hi.to(self.device, non_blocking=True)
+                        de = he.to(self.device, non_blocking=True)
+                    ev_done = torch.cuda.Event()
+                    ev_done.record(copy_stream)
+                    torch.cuda.current_stream(self.device).wait_event(ev_done)
+                    di.record_stream(torch.cuda.current_stream(self.device))
+                    de.record_stream(torch.cuda.current_stream(self.device))
+                else:
+                    di, de = hi, he
+                pend, pend_chunks = [], 0
+                return di, de, meta
+
+            while futs:
+                idx, img, ev, n = futs.pop(0).result()
+                top_up()
+                nch = (n // T + (1 if n % T else 0)) if n >= T else 1
+                pend.append((idx, img, ev, n))
+                pend_chunks += nch
+                if pend_chunks >= self.batch_chunks:
+                    yield emit()
+            if pend:
+                yield emit()
+
+
+def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch_chunks: int = 256, workers: int = 8,
+                   device_metrics: bool = True, verbose: bool = False):
+    """End-to-end evaluation from a `path,label` CSV of feature files: streaming loader -> batched forward ->
+    ordered scores -> AUC / AP (on the device when `device_metrics`).  Returns a dict with the metrics, the
+    per-video scores and a wall-clock phase breakdown."""
+    import time
+    dataset = dataset or args.dataset
+    with open(args.test_list, newline='') as f:
+        rows = list(csv.DictReader(f))
+    paths, labels = [r['path'] for r in rows], [r['label'] for r in rows]
+    pipe = FeatureFilePipeline(paths, labels, args.visual_length, EVENT_DIR[dataset], device, batch_chunks, workers)
+    model.eval()
+    t0 = time.perf_counter()
+    outs, metas = [], []
+    with torch.no_grad():
+        for img, ev, meta in pipe.batches():
+            o = model(img, ev, None, None, None)
+            outs.append(o['logits'].reshape(img.shape[0], -1))
+            metas.append(meta)
+    T = args.visual_length
+    pieces = []
+    for lg, meta in zip(outs, metas):
+        off = 0
+        for _, n, nch in meta:
+            pieces.append(lg[off:off + nch].reshape(-1)[:n])
+            off += nch
+    scores_dev = torch.sigmoid(torch.cat(pieces))
+    if scores_dev.is_cuda:
+        torch.cuda.synchronize(scores_dev.device)
+    t1 = time.perf_counter()
+    res: Dict[str, object] = {}
+    if device_metrics:
+        roc, ap = device_auc_ap(scores_dev, torch.as_tensor(gt))
+        res.update(roc=roc, ap=ap)
+    scores_host = scores_dev.float().cpu().numpy()
+    t2 = time.perf_counter()
+    lens = [n for meta in metas for _, n, _ in meta]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    per_video = [scores_host[offs[i]:offs[i + 1]] for i in range(len(lens))]
+    if not device_metrics:
+        res.update(evaluate_scores(per_video, labels, gt, dataset, verbose=verbose))
+    res.update(scores=per_video, classes=labels, snippets=int(offs[-1]),
+               seconds={"load+h2d+forward": t1 - t0, "metrics": t2 - t1})
+    return res
 
 
 def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,

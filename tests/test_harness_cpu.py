@@ -146,3 +146,23 @@ def test_perturbation_sweep_reproduces_reference_run_test(golden_dir):
         assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
         assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
     assert len(cache) == len(lengths)      # the clean forwards ran once, not once per level
+
+
+def test_streaming_file_pipeline_matches_per_video_loop(config1):
+    """FeatureFilePipeline + evaluate_files (threads, cross-video packing, empty-chunk drop, device metric tail)
+    vs the reference-pattern loop on the same .npy files."""
+    g, args, gt, sd = config1
+    model = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    res = harness.evaluate_files(args, model, gt, "cpu", batch_chunks=6, workers=3)
+    scores = np.concatenate(res["scores"])
+    assert res["snippets"] == int(g["lengths"].sum()) and scores.shape == g["scores"].shape
+    assert np.abs(scores - g["scores"]).max() < 2e-6
+    assert abs(res["roc"] - float(g["roc"])) < 1e-4 and abs(res["ap"] - float(g["ap"])) < 1e-4
+    assert res["classes"] == [str(c) for c in g["classes"]]
+    # chunk accounting: a 256-snippet video occupies ONE chunk here (the reference's all-zero second chunk is dropped)
+    pipe = harness.FeatureFilePipeline([p for p in open(args.test_list).read().split()[1:] for p in [p.split(",")[0]]],
+                                       ["x"] * 16, 256, "event_thr_10", "cpu", batch_chunks=1000)
+    (img, ev, meta), = list(pipe.batches())
+    by_len = {n: nch for _, n, nch in meta}
+    assert by_len[256] == 1 and by_len[257] == 2 and by_len[512] == 2 and by_len[37] == 1 and by_len[1500] == 6
+    assert img.shape[0] == sum(nch for _, _, nch in meta)
