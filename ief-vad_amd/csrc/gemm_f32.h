@@ -54,29 +54,32 @@ struct GemmArgs {
 
 
 // Residual operand of the EPI_BIAS_RESID / EPI_REFINE epilogues, fetched in accumulator layout.
-__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& args, const GemmProblem& P, f32x16 (&res)[2][2],
+// TM x TN = 32x32 accumulators per wave (wave tile 32 TM x 32 TN); (wr, wc) = wave position in the 2x2 wave grid.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& args, const GemmProblem& P, f32x16 (&res)[TM][TN],
                                                        int m0, int n0, int wr, int wc, int i, int h) {
     const int epi = args.epi, ldc = args.ldc;
     if (epi == EPI_BIAS_RESID || epi == EPI_REFINE) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    res[a][b][r] = P.R[(size_t)(m0 + wr * 64 + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2)) * ldc +
-                                       n0 + wc * 64 + b * 32 + i];
+                    res[a][b][r] = P.R[(size_t)(m0 + wr * 32 * TM + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2)) * ldc +
+                                       n0 + wc * 32 * TN + b * 32 + i];
     }
 }
 
 // Epilogue.  Accumulator map (32x32 tile): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, const GemmProblem& P, f32x16 (&acc)[2][2],
-                                              f32x16 (&res)[2][2], int m0, int n0, int wr, int wc, int i, int h) {
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, const GemmProblem& P, f32x16 (&acc)[TM][TN],
+                                              f32x16 (&res)[TM][TN], int m0, int n0, int wr, int wc, int i, int h) {
     const int epi = args.epi, ldc = args.ldc;
     const float alpha = args.alpha;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wc * 64 + b * 32 + i;
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wc * 32 * TN + b * 32 + i;
         const float bv = P.bias[n];
         float* Cb = P.C;
         int nn = n;
@@ -84,8 +87,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, const GemmPr
         if (epi == EPI_HEADS && n >= IEF_D) { Cb = P.C2; nn = n - IEF_D; }
         if (epi == EPI_QKV && n < args.qcols) scale = alpha;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int mb = m0 + wr * 64 + a * 32 + 4 * h;
+        for (int a = 0; a < TM; ++a) {
+            const int mb = m0 + wr * 32 * TM + a * 32 + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -213,10 +216,91 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_kernel(GemmArgs args) 
     }
     // last tile: nothing left to stage; epilogues that read a residual prefetch it here, under the MFMAs
     f32x16 res[2][2];
-    gemm_prefetch_residual(args, P, res, m0, n0, wr, wc, i, h);
+    gemm_prefetch_residual<2, 2>(args, P, res, m0, n0, wr, wc, i, h);
     GEMM_TILE_BODY(false)
 #undef GEMM_TILE_BODY
 #undef GLDS16
 
-    gemm_epilogue(args, P, acc, res, m0, n0, wr, wc, i, h);
+    gemm_epilogue<2, 2>(args, P, acc, res, m0, n0, wr, wc, i, h);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Low-latency variant for small M (the reference's per-video call pattern: B = 1 .. a few chunks): 64 x 64 block
+// tile, 4 waves as 2 x 2 of one 32x32 accumulator, BK = 32, 32 KB LDS.  A launch has 4x the blocks and each
+// block a quarter of the MFMA chain of the 128 x 128 kernel (24 k-tiles x 16 MFMAs = 10 us instead of 41 us),
+// which is what bounds the time when the grid does not fill 256 CUs anyway.  Same LDS image, same staging and
+// the same k summation order per output element: results are bit-identical to iefvad_gemm_f32_kernel.
+// ------------------------------------------------------------------------------------------------------------
+#define GEMS_BM 64
+#define GEMS_BN 64
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_small_kernel(GemmArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GEMS_BM + GEMS_BN) * GEMM_BK];   // 32 KB
+    const GemmProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GEMS_BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GEMS_BM, n0 = tn * GEMS_BN;
+    const int K = args.K, lda = args.lda;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int srow = t >> 3, sch = t & 7;
+    const int fsw = (i >> 1) & 7;
+    const int aoff = (wr * 32 + i) * GEMM_BK, boff = (wc * 32 + i) * GEMM_BK;
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+    const int nk = K / GEMM_BK;
+    const int ssw = (srow >> 1) & 7;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
+                                                       (int)((GEMS_BM - 1) * lda + K) * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
+                                                       (int)((GEMS_BN - 1) * K + K) * 4, 0x00020000);
+    const int voA = (srow * lda + ((sch ^ ssw) << 2)) * 4;
+    const int voW = (srow * K + ((sch ^ ssw) << 2)) * 4;
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * GEMM_BK;
+#define GLDS16(rs, vo, so, lp) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+#define GEMS_STAGE(kk, buf)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+        GLDS16(rsA, voA, (32 * j * lda + (kk)) * 4, smem + (buf) * GEMS_BM * GEMM_BK + wbase + 32 * j * GEMM_BK); \
+        GLDS16(rsW, voW, (32 * j * K + (kk)) * 4,                                                        \
+               smem + 2 * GEMS_BM * GEMM_BK + (buf) * GEMS_BN * GEMM_BK + wbase + 32 * j * GEMM_BK);     \
+    }
+    GEMS_STAGE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    f32x16 res[1][1];
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            GEMS_STAGE((kt + 1) * GEMM_BK, cur ^ 1)
+        } else {
+            gemm_prefetch_residual<1, 1>(args, P, res, m0, n0, wr, wc, i, h);
+        }
+        const float* As = smem + cur * GEMS_BM * GEMM_BK;
+        const float* Ws = smem + 2 * GEMS_BM * GEMM_BK + cur * GEMS_BN * GEMM_BK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = ((2 * s + h) ^ fsw) << 2;
+            const f32x4 fa = *(const f32x4*)(As + aoff + ch);
+            const f32x4 fb = *(const f32x4*)(Ws + boff + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[0][0], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#undef GEMS_STAGE
+#undef GLDS16
+    gemm_epilogue<1, 1>(args, P, acc, res, m0, n0, wr, wc, i, h);
 }

@@ -266,9 +266,17 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
     if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
         return fail("gemm: shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
                     GEMM_BK);
-    dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
+    // a grid that cannot fill the 256 CUs is bounded by one block's MFMA chain: use the 64x64-tile kernel
+    // (4x the blocks, a quarter of the chain, bit-identical results)
+    const int big_blocks = (a.M / GEMM_BM) * (a.N / GEMM_BN) * nz;
     hipEvent_t e = tm.begin(stage);
-    hipLaunchKernelGGL(iefvad_gemm_f32_kernel, grid, dim3(256), 0, stream, a);
+    if (big_blocks < 256) {
+        dim3 grid((a.M / GEMS_BM) * (a.N / GEMS_BN), 1, nz);
+        hipLaunchKernelGGL(iefvad_gemm_f32_small_kernel, grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid((a.M / GEMM_BM) * (a.N / GEMM_BN), 1, nz);
+        hipLaunchKernelGGL(iefvad_gemm_f32_kernel, grid, dim3(256), 0, stream, a);
+    }
     tm.end(e);
     tm.gemm_launches += 1;
     HIP_TRY(hipGetLastError());

@@ -42,7 +42,7 @@ def test_gemm_kernel_matches_fp64():
     transposed accumulator map.  Tolerance: fp32 k-ordered fma chain, K=768 -> ~1e-7 * sum|a*b|."""
     lib = iefvad_amd.lib.load_library()
     rng = np.random.default_rng(0)
-    for (M, N, K) in [(256, 768, 768), (512, 2304, 768), (128, 128, 32)]:
+    for (M, N, K) in [(256, 768, 768), (512, 2304, 768), (128, 128, 32), (8192, 768, 768)]:   # last one: 128x128-tile kernel
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = rng.standard_normal((N, K)).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32)
@@ -55,6 +55,25 @@ def test_gemm_kernel_matches_fp64():
         ref = A.astype(np.float64) @ W.astype(np.float64).T + b
         err = np.abs(dC.cpu().numpy() - ref).max()
         assert err < 2e-4 * np.sqrt(K / 768.0) + 1e-5, (M, N, K, err)
+
+
+def test_small_and_large_tile_gemm_kernels_are_bit_identical():
+    """The library picks a 64x64-tile kernel when the grid cannot fill the chip and the 128x128-tile kernel
+    otherwise; both sum k in the same order, so the same rows give the same bits whatever M they arrive in."""
+    lib = iefvad_amd.lib.load_library()
+    rng = np.random.default_rng(1)
+    M, N, K = 8192, 768, 768
+    A = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    W = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
+    big = torch.empty(M, N, device="cuda")
+    small = torch.empty(256, N, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.iefvad_gemm_bias(A.data_ptr(), W.data_ptr(), b.data_ptr(), big.data_ptr(), M, N, K, 0, st) == 0
+    assert lib.iefvad_gemm_bias(A[1024:1280].contiguous().data_ptr(), W.data_ptr(), b.data_ptr(), small.data_ptr(),
+                                256, N, K, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(big[1024:1280], small)
 
 
 @pytest.mark.parametrize("name", H.golden_cases())
