@@ -13,7 +13,7 @@ blocks (videos shard embarrassingly), so scaling is weak and `valu
 aggregate.  Weights are seeded synthetic tensors of the reference architecture (K=10, nu=8, StudentT).
 
 The JSON line also carries
-  roofline      the dense-projection GEMM kernel (iefvad_gemm_f32_kernel, >90 % of device time):
+  roofline      the dense-projection GEMM kernel (iefvad_gemm_f32_t256_kernel, ~89 % of device time):
                 algorithmic GEMM FLOPs of a step / sum of that kernel's launch durations in the step,
                 timed with hipEvents on the launch stream inside the timed region, against the exact-fp32
                 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
@@ -174,7 +174,7 @@ def main():
                        "parallelism": f"video-sharded x{world}, score all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": "iefvad_gemm_f32_kernel" if a.compute == "f32" else "iefvad_gemm_bf16_kernel",
+                         "kernel": "iefvad_gemm_f32_t256_kernel" if a.compute == "f32" else "iefvad_gemm_bf16_kernel",
                          "launches_per_step": launches,
                          "avg_launch_ms": gemm_ms / launches,
                          "flops_per_launch": gemm_flops / launches},

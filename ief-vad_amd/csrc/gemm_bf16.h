@@ -217,8 +217,13 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 #define GB2_EPI_LD 132                              // padded row (floats) of the per-wave epilogue image (32 x 128)
 #define GB2_LDS_BYTES (GB2_STAGES * GB2_SLOT * 4)   // 73,728 B
 
-__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// One body, two element types: F32 = false -> bf16 operands (32 elements per 64-byte row, v_mfma_f32_32x32x16_bf16);
+// F32 = true -> fp32 operands (16 elements per row; each 16-byte fragment feeds four v_mfma_f32_32x32x2_f32, lane
+// half h taking k = 8s+4h..+3 exactly as iefvad_gemm_f32_kernel does, so the fp32 results are bit-identical to it).
+template <bool F32>
+__device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* smem) {
+    constexpr int EB = F32 ? 4 : 2;                     // bytes per operand element
+    constexpr int BKE = 64 / EB;                        // elements per k-tile row (64 bytes)
     const GemmBProblem& P = args.p[blockIdx.z];
     const int ntn = args.N / GB2_BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -234,12 +239,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args
     // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3
     const int srow = t >> 2, sch = t & 3;
     const int ssw = (srow >> 2) & 3;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
-                                                       (int)((GB2_BM - 1) * lda + K) * 2, 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
-                                                       (int)((GB2_BN - 1) * K + K) * 2, 0x00020000);
-    const int voA = srow * lda * 2 + ((sch ^ ssw) << 4);
-    const int voW = srow * K * 2 + ((sch ^ ssw) << 4);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * EB), 0,
+                                                       (int)((GB2_BM - 1) * lda + K) * EB, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * EB), 0,
+                                                       (int)((GB2_BN - 1) * K + K) * EB, 0x00020000);
+    const int voA = srow * lda * EB + ((sch ^ ssw) << 4);
+    const int voW = srow * K * EB + ((sch ^ ssw) << 4);
     const int wbase = __builtin_amdgcn_readfirstlane(wave) * 16 * 16;    // this wave's 16 rows x 64 B, 4-byte units
 #define GLDS16(rs, vo, so, lp) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
@@ -247,9 +252,9 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args
     {                                                                                                 \
         float* Ad = smem + (slotbase) + wbase;                                                        \
         float* Wd = Ad + GB2_BM * 16;                                                                 \
-        const int kk = (tile) * GB2_BK;                                                               \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) GLDS16(rsA, voA, (64 * j * lda + kk) * 2, Ad + 64 * j * 16); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(rsW, voW, (64 * j * K + kk) * 2, Wd + 64 * j * 16);   \
+        const int kk = (tile) * BKE;                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) GLDS16(rsA, voA, (64 * j * lda + kk) * EB, Ad + 64 * j * 16); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(rsW, voW, (64 * j * K + kk) * EB, Wd + 64 * j * 16);   \
     }
 
     const int fsw = (i >> 2) & 3;
@@ -270,19 +275,28 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args
 #define GB2_COMPUTE(slotbase)                                                                               \
     {                                                                                                       \
         const float* S = smem + (slotbase);                                                                 \
-        bf16x8 fa[2][2], fb[2][4];                                                                          \
+        f32x4 fa[2][2], fb[2][4];   /* 16-byte fragments: 4 fp32 or 8 bf16 */                                \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
             const int ch = ((2 * s + h) ^ fsw) << 2;                                                        \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) fa[s][x] = *(const bf16x8*)(S + aoff[x] + ch);    \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x) fb[s][x] = *(const bf16x8*)(S + boff[x] + ch);    \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) fa[s][x] = *(const f32x4*)(S + aoff[x] + ch);     \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) fb[s][x] = *(const f32x4*)(S + boff[x] + ch);     \
         }                                                                                                   \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                   \
-                _Pragma("unroll") for (int b = 0; b < 4; ++b)                                               \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][a], fb[s][b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
+            if constexpr (F32) {                                                                            \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
+                    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
+                        _Pragma("unroll") for (int b = 0; b < 4; ++b)                                       \
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][a][e], fb[s][b][e], acc[a][b], 0, 0, 0); \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int a = 0; a < 2; ++a)                                               \
+                    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                \
+                            __builtin_bit_cast(bf16x8, fa[s][a]), __builtin_bit_cast(bf16x8, fb[s][b]), acc[a][b], 0, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
     }
 
-    const int nk = K / GB2_BK;       // >= 2
+    const int nk = K / BKE;          // >= 2
     int s0 = 0, s1 = GB2_SLOT, s2 = 2 * GB2_SLOT;     // slot of tile kt, kt+1, kt+2 (float offsets), rotated each tile
     GB2_STAGE(0, s0)
     GB2_STAGE(1, s1)
@@ -357,4 +371,15 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_t256_body<false>(args, smem);
+}
+
+// fp32 operands on the same 128x256 / 3-slot-ring structure (A and W of GemmBProblem then point to fp32 data)
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_t256_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_t256_body<true>(args, smem);
 }

@@ -16,7 +16,6 @@
 #include "attention_bf16.h"
 #include "common.h"
 #include "gemm_f32.h"
-#include "gemm_f32_ring.h"
 #include "gemm_bf16.h"
 #include "rowops.h"
 
@@ -113,6 +112,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GB2_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e != hipSuccess) {
         delete h;
@@ -266,11 +268,25 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
     if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
         return fail("gemm: shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
                     GEMM_BK);
-    // a grid that cannot fill the 256 CUs is bounded by one block's MFMA chain: use the 64x64-tile kernel
-    // (4x the blocks, a quarter of the chain, bit-identical results)
-    const int big_blocks = (a.M / GEMM_BM) * (a.N / GEMM_BN) * nz;
+    // Three tilings of the same contraction, bit-identical to each other (same k order per output element):
+    //   128x256 / 3-slot ring (iefvad_gemm_f32_t256_kernel)  the throughput kernel, when its grid fills the chip;
+    //   128x128 / double buffer (iefvad_gemm_f32_kernel)      mid-size grids or N not a multiple of 256;
+    //   64x64 (iefvad_gemm_f32_small_kernel)                  small M: 4x the blocks, a quarter of the MFMA chain.
+    const int blocks128 = (a.M / GEMM_BM) * (a.N / GEMM_BN) * nz;
+    const bool t256_ok = (a.N % GB2_BN == 0) && (a.K % 16 == 0) && (a.K >= 32);
+    const int blocks256 = t256_ok ? (a.M / GB2_BM) * (a.N / GB2_BN) * nz : 0;
     hipEvent_t e = tm.begin(stage);
-    if (big_blocks < 256) {
+    if (blocks256 >= 256) {
+        GemmBArgs b;
+        memset(&b, 0, sizeof(b));
+        b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldc = a.ldc; b.epi = a.epi; b.alpha = a.alpha; b.qcols = a.qcols;
+        for (int m = 0; m < nz; ++m) {
+            b.p[m].A = (const bf16_t*)a.p[m].A; b.p[m].W = (const bf16_t*)a.p[m].W;     // fp32 data behind the typed pointer
+            b.p[m].bias = a.p[m].bias; b.p[m].C = a.p[m].C; b.p[m].R = a.p[m].R; b.p[m].C2 = a.p[m].C2;
+        }
+        dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
+        hipLaunchKernelGGL(iefvad_gemm_f32_t256_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, b);
+    } else if (blocks128 < 256) {
         dim3 grid((a.M / GEMS_BM) * (a.N / GEMS_BN), 1, nz);
         hipLaunchKernelGGL(iefvad_gemm_f32_small_kernel, grid, dim3(256), 0, stream, a);
     } else {

@@ -103,3 +103,35 @@ def test_xd_shaped_set_auc_and_ap_parity_bf16():
     for k in ("roc", "ap", "ano_auc"):
         assert abs(r_gpu[k] - r_cpu[k]) < 1e-4, (k, r_gpu[k], r_cpu[k])
     print("config-3 shape: snippets", total, "max|dscore|", dmax, "AUC", r_gpu["roc"], r_cpu["roc"], "AP", r_gpu["ap"], r_cpu["ap"])
+
+
+def test_config5_k5_shang_msad_shaped_bf16():
+    """BASELINE config 5: K=5 refinement steps, ShanghaiTech + MSAD sized set (438 videos, 17,732 snippets --
+    the exact totals of list/{shang,msad}/rgb/vitl/gt.npy / 16), bf16 projections; AUC / AP vs the fp32 oracle."""
+    seed = 5
+    lengths = synth.lognormal_lengths(seed, 438, 17732, lo=4, hi=400)
+    keys = harness.CLASS_KEYS['msad']
+    classes = [keys[i % len(keys)] for i in range(438)]
+    total = int(lengths.sum())
+    gt = synth.make_gt(seed, total)
+    sd = synth.make_state_dict(19, 768, 2, 5)
+
+    def items():
+        for i, (n, c) in enumerate(zip(lengths, classes)):
+            img, ev = synth.make_video(seed, i, int(n))
+            ci, _ = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), (c,), torch.tensor([int(n)])
+
+    model = make_model(2, 5, 0.5, "StudentT", 8, sd, outputs="scores")
+    s_gpu, _, _, _ = harness.score_loader(model, items(), 256, "cuda:0", "msad", batch_chunks=128)
+    torch.set_num_threads(16)
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig(num_refinement_steps=5))
+    s_cpu, _, _, _ = harness.score_loader(oracle, items(), 256, "cpu", "msad", batch_chunks=8)
+    a, b = np.concatenate(s_gpu), np.concatenate(s_cpu)
+    assert a.shape == b.shape == (total,)
+    assert float(np.abs(a - b).max()) <= TOL_SIGMOID_BF16
+    r_gpu = harness.evaluate_scores(s_gpu, classes, gt, "msad", verbose=False)
+    r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "msad", verbose=False)
+    for k in ("roc", "ap", "ano_auc"):
+        assert abs(r_gpu[k] - r_cpu[k]) < 1e-4, (k, r_gpu[k], r_cpu[k])

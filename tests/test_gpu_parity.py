@@ -42,7 +42,7 @@ def test_gemm_kernel_matches_fp64():
     transposed accumulator map.  Tolerance: fp32 k-ordered fma chain, K=768 -> ~1e-7 * sum|a*b|."""
     lib = iefvad_amd.lib.load_library()
     rng = np.random.default_rng(0)
-    for (M, N, K) in [(256, 768, 768), (512, 2304, 768), (128, 128, 32), (8192, 768, 768)]:   # last one: 128x128-tile kernel
+    for (M, N, K) in [(256, 768, 768), (512, 2304, 768), (128, 128, 32), (8192, 768, 768)]:   # small-tile and 128x128 kernels
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = rng.standard_normal((N, K)).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32)
@@ -57,23 +57,31 @@ def test_gemm_kernel_matches_fp64():
         assert err < 2e-4 * np.sqrt(K / 768.0) + 1e-5, (M, N, K, err)
 
 
-def test_small_and_large_tile_gemm_kernels_are_bit_identical():
-    """The library picks a 64x64-tile kernel when the grid cannot fill the chip and the 128x128-tile kernel
-    otherwise; both sum k in the same order, so the same rows give the same bits whatever M they arrive in."""
+def test_three_gemm_tilings_are_bit_identical():
+    """The library picks the 128x256 ring kernel when its grid fills the chip, the 128x128 kernel for mid-size
+    grids and a 64x64-tile kernel for small M; all sum k in the same order, so the same rows give the same
+    bits whatever M they arrive in (this is what makes micro-batching and cross-video packing exact)."""
     lib = iefvad_amd.lib.load_library()
     rng = np.random.default_rng(1)
-    M, N, K = 8192, 768, 768
+    M, N, K = 16384, 768, 768
     A = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
     W = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
     b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
-    big = torch.empty(M, N, device="cuda")
-    small = torch.empty(256, N, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert lib.iefvad_gemm_bias(A.data_ptr(), W.data_ptr(), b.data_ptr(), big.data_ptr(), M, N, K, 0, st) == 0
-    assert lib.iefvad_gemm_bias(A[1024:1280].contiguous().data_ptr(), W.data_ptr(), b.data_ptr(), small.data_ptr(),
-                                256, N, K, 0, st) == 0
+
+    def gemm(rows):
+        out = torch.empty(rows.shape[0], N, device="cuda")
+        assert lib.iefvad_gemm_bias(rows.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), rows.shape[0], N, K, 0, st) == 0
+        return out
+
+    t256 = gemm(A)                             # 128 x 3 = 384 blocks of 128x256  -> ring kernel
+    t128 = gemm(A[:8192].contiguous())         # 64 x 6 = 384 blocks of 128x128   -> double-buffer kernel
+    t64 = gemm(A[1024:1280].contiguous())      # 2 x 6 blocks                      -> small-tile kernel
     torch.cuda.synchronize()
-    assert torch.equal(big[1024:1280], small)
+    assert torch.equal(t256[:8192], t128)
+    assert torch.equal(t256[1024:1280], t64)
+    ref = A[:256].double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    assert (t256[:256].double().cpu() - ref).abs().max().item() < 2e-4
 
 
 @pytest.mark.parametrize("name", H.golden_cases())

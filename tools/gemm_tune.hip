@@ -8,7 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include "../ief-vad_amd/csrc/gemm_f32.h"
-#include "../ief-vad_amd/csrc/gemm_f32_ring.h"
+#include "../ief-vad_amd/csrc/gemm_bf16.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -135,7 +135,15 @@ static float time_variant(const Variant& v, GemmArgs g, unsigned long long* dclk
     for (int it = 0; it < iters; ++it) {
         switch (v.kind) {
             case -1: hipLaunchKernelGGL(iefvad_gemm_f32_kernel, grid, dim3(256), 0, 0, g); break;
-            case -2: hipLaunchKernelGGL(iefvad_gemm_f32_ring_kernel, grid, dim3(256), 0, 0, g); break;
+            case -3: {
+                GemmBArgs b; memset(&b, 0, sizeof(b));
+                b.M = g.M; b.N = g.N; b.K = g.K; b.lda = g.lda; b.ldc = g.ldc; b.epi = g.epi; b.alpha = g.alpha; b.qcols = g.qcols;
+                for (int m = 0; m < 2; ++m) { b.p[m].A = (const bf16_t*)g.p[m].A; b.p[m].W = (const bf16_t*)g.p[m].W; b.p[m].bias = g.p[m].bias;
+                                              b.p[m].C = g.p[m].C; b.p[m].R = g.p[m].R; b.p[m].C2 = g.p[m].C2; }
+                dim3 grid2((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
+                hipLaunchKernelGGL(iefvad_gemm_f32_t256_kernel, grid2, dim3(256), GB2_LDS_BYTES, 0, b);
+                break;
+            }
             case 0: hipLaunchKernelGGL(gemm_abl<0>, grid, dim3(256), 0, 0, g, dclk); break;
             case 1: hipLaunchKernelGGL(gemm_abl<1>, grid, dim3(256), 0, 0, g, dclk); break;
             case 2: hipLaunchKernelGGL(gemm_abl<2>, grid, dim3(256), 0, 0, g, dclk); break;
@@ -160,6 +168,7 @@ static float time_variant(const Variant& v, GemmArgs g, unsigned long long* dclk
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32768, K = 768;
     const int iters = argc > 2 ? atoi(argv[2]) : 100, rounds = 5;
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     const int Ns[2] = {768, 2304};
     float *A, *W, *bias, *C; unsigned long long* dclk;
     CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&W, (size_t)2304 * K * 4)); CK(hipMalloc(&bias, 2304 * 4));
@@ -169,7 +178,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W, h.data(), (size_t)2304 * K * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(bias, h.data(), 2304 * 4, hipMemcpyHostToDevice));
-    const Variant vs[] = {{"v1 full", 0, EPI_BIAS, 1}, {"LIB bias", -1, EPI_BIAS, 1}, {"RING bias", -2, EPI_BIAS, 1}, {"RING refine R=C", -2, EPI_REFINE, 1}, {"RING bias z=2", -2, EPI_BIAS, 2}, {"LIB relu", -1, EPI_BIAS_RELU, 1},
+    const Variant vs[] = {{"v1 full", 0, EPI_BIAS, 1}, {"LIB bias", -1, EPI_BIAS, 1}, {"T256 bias", -3, EPI_BIAS, 1}, {"T256 refine R=C", -3, EPI_REFINE, 1}, {"T256 relu", -3, EPI_BIAS_RELU, 1}, {"T256 resid R=C", -3, EPI_BIAS_RESID, 1}, {"T256 bias z=2", -3, EPI_BIAS, 2}, {"LIB relu", -1, EPI_BIAS_RELU, 1},
                           {"LIB refine R=C", -1, EPI_REFINE, 1}, {"LIB resid R=C", -1, EPI_BIAS_RESID, 1},
                           {"LIB bias z=2", -1, EPI_BIAS, 2}, {"v1 no stores", 1, EPI_BIAS, 1}, {"v1 loads, no ds_write", 8, EPI_BIAS, 1}, {"v1 ds_write, no loads", 16, EPI_BIAS, 1}, {"v1 no loads", 2, EPI_BIAS, 1},
                           {"v1 no loads/stores", 3, EPI_BIAS, 1}, {"v1 mfma only", 7, EPI_BIAS, 1}};
@@ -189,7 +198,7 @@ int main(int argc, char** argv) {
             CK(hipMemset(C, 0, c1.size() * 4));
             time_variant(vs[2], g, dclk, 1); CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
             bad = 0; for (size_t q = 0; q < c1.size(); ++q) bad += (c1[q] != c2[q]);
-            printf("N=%d: ring kernel vs v1: %zu mismatching elements of %zu\n", g.N, bad, c1.size());
+            printf("N=%d: t256 kernel vs v1: %zu mismatching elements of %zu\n", g.N, bad, c1.size());
         }
         std::vector<std::vector<float>> t(nv);
         std::vector<double> clkv(nv), cycv(nv);
