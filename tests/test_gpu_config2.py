@@ -131,3 +131,33 @@ def test_perturbation_sweep_on_gpu_matches_reference_capture(golden_dir):
         assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), tag
         assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
         assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
+
+
+def test_full_config4_batch_properties():
+    """BASELINE config 4 at its full single-GPU size (B = 8192 chunks = 2,097,152 snippets, inputs resident in
+    HBM), checked through size-independent properties: every score finite; chunks picked from the big call
+    are bit-identical to the same chunks forwarded alone (micro-batching, tile selection and position in the
+    batch do not matter); duplicated chunks give duplicated scores."""
+    sd = synth.make_state_dict(9)
+    model = gpu_model(sd, outputs="scores")
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(1234)
+    B = 8192
+    img = torch.randn(B, 256, 768, device="cuda:0", generator=g) * 0.45
+    ev = torch.randn(B, 256, 768, device="cuda:0", generator=g) * 0.45
+    img[4097], ev[4097] = img[11], ev[11]                     # a duplicated chunk far away in another micro-batch
+    with torch.no_grad():
+        out = model(img, ev, None, None, None)
+    lg = out["logits"]
+    assert lg.shape == (B, 256, 1) and bool(torch.isfinite(lg).all())
+    assert bool(torch.isfinite(out["w_i_mean"]).all()) and bool(torch.isfinite(out["w_e_mean"]).all())
+    assert torch.equal(lg[11], lg[4097])
+    s = torch.sigmoid(lg)
+    assert 0.0 < float(s.min()) and float(s.max()) < 1.0
+    assert float((out["w_i_mean"] + out["w_e_mean"] - 1.0).abs().max()) < 1e-5      # n_i + n_e = 1 up to eps
+    pick = [0, 255, 256, 4097, 8191]
+    with torch.no_grad():
+        sub = model(img[pick].contiguous(), ev[pick].contiguous(), None, None, None)
+    assert torch.equal(sub["logits"], lg[pick])
+    del img, ev, out, sub
+    torch.cuda.empty_cache()
