@@ -305,7 +305,6 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     int kt = 0;
     for (; kt + 2 < nk; ++kt) {
         GB2_STAGE(kt + 2, s2)                         // s2 held tile kt-1: every wave passed the barrier after reading it
-        __builtin_amdgcn_sched_barrier(0);
         GB2_COMPUTE(s0)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own DMAs of tile kt+1 landed; tile kt+2's six stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
