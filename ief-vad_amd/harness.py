@@ -272,9 +272,10 @@ class FeatureFilePipeline:
         self.batch_chunks, self.workers, self.prefetch = batch_chunks, workers, prefetch
 
     def _load(self, idx):
+        # memory-mapped read: the only copy of the payload is page cache -> pinned staging buffer (made by the consumer)
         p = self.paths[idx]
-        img = np.load(p)
-        ev = np.load(p.replace('rgb', self.event_dir))
+        img = np.load(p, mmap_mode='r')
+        ev = np.load(p.replace('rgb', self.event_dir), mmap_mode='r')
         n = int(img.shape[0])
         if np.isnan(img).any():
             img = np.nan_to_num(img, nan=0.0)
@@ -310,8 +311,8 @@ class FeatureFilePipeline:
                 meta, off = [], 0
                 for idx, img, ev, n in pend:
                     nch = n // T + (1 if n % T else 0) if n >= T else 1
-                    hi[off:off + nch].reshape(-1, D)[:n] = torch.from_numpy(img.astype(dt, copy=False))
-                    he[off:off + nch].reshape(-1, D)[:n] = torch.from_numpy(ev.astype(dt, copy=False))
+                    hi[off:off + nch].reshape(-1, D).numpy()[:n] = img
+                    he[off:off + nch].reshape(-1, D).numpy()[:n] = ev
                     meta.append((idx, n, nch))
                     off += nch
                 if copy_stream is not None:
