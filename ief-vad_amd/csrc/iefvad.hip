@@ -589,6 +589,7 @@ extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const voi
     times->fusion_ms = acc[ST_FUSION];
     times->refine_gemm_ms = acc[ST_REFINE];
     times->scorer_ms = acc[ST_SCORER];
+    times->cast_ms = acc[ST_CAST];
     times->gemm_launches = tm.gemm_launches;
     return 0;
 }

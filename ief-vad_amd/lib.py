@@ -55,7 +55,7 @@ class StageTimes(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("qkv_gemm_ms", C.c_float), ("attention_ms", C.c_float),
                 ("out_gemm_ms", C.c_float), ("layernorm_ms", C.c_float), ("head_gemm_ms", C.c_float),
                 ("fusion_ms", C.c_float), ("refine_gemm_ms", C.c_float), ("scorer_ms", C.c_float),
-                ("gemm_launches", C.c_int32)]
+                ("cast_ms", C.c_float), ("gemm_launches", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

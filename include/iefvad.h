@@ -116,6 +116,7 @@ typedef struct iefvad_stage_times {
     float fusion_ms;
     float refine_gemm_ms;
     float scorer_ms;
+    float cast_ms;           /* input casts and bf16 operand copies */
     int32_t gemm_launches;   /* number of dense-projection GEMM launches in the pass */
 } iefvad_stage_times;
 
