@@ -172,3 +172,49 @@ def test_literal_overflow_semantics():
     ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_layers=1, num_refinement_steps=0))
     assert np.isnan(ref["w_i"].numpy()).all() and np.isnan(out["w_i"]).all()
     assert np.isnan(out["logits"]).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_configs_vs_oracle(seed):
+    """Random (L, K, noise model, nu, lambda, B, input dtype, input scale) draws against the CPU oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.integers(1, 4))
+    K = int(rng.integers(0, 5))
+    noise = ["StudentT", "Gaussian"][int(rng.integers(0, 2))]
+    nu = int(rng.integers(2, 12))
+    lam = float(rng.choice([0.1, 0.25, 0.5, 0.9]))
+    B = int(rng.integers(1, 4))
+    scale = float(rng.choice([0.05, 0.45, 2.0]))
+    dt = [torch.float32, torch.float16][int(rng.integers(0, 2))]
+    sd = synth.make_state_dict(2000 + seed, 768, L, K)
+    img, ev = synth.make_inputs(3000 + seed, B, scale=scale)
+    ti, te = torch.from_numpy(img).to(dt), torch.from_numpy(ev).to(dt)
+    model = make_model(L, K, lam, noise, nu, sd)
+    with torch.no_grad():
+        out = model(ti.cuda(), te.cuda(), None, None, None)
+    ref = orc.forward(sd, ti, te, orc.OracleConfig(num_layers=L, num_refinement_steps=K, lambda_ref=lam,
+                                                   noise_model=noise, nu=nu))
+    for k in iefvad_amd.OUTPUT_KEYS:
+        d = (out[k].cpu() - ref[k]).abs().max().item()
+        assert d <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), (k, d, dict(L=L, K=K, noise=noise, nu=nu, lam=lam, B=B))
+    ds = (torch.sigmoid(out["logits"].cpu()) - torch.sigmoid(ref["logits"])).abs().max().item()
+    assert ds <= H.TOL_SIGMOID
+
+
+def test_non_finite_inputs_propagate_like_the_reference():
+    """An inf in one snippet of one modality: attention mixes it into every row of that chunk, so the
+    reference's outputs are NaN for the whole chunk of that modality and the fusion makes the chunk's scores
+    NaN; other chunks are untouched.  The HIP path must produce the same NaN pattern and the same finite values."""
+    sd = synth.make_state_dict(81, 768, 2, 2)
+    img, ev = synth.make_inputs(82, 3)
+    img[1, 17, 5] = np.inf
+    model = make_model(2, 2, 0.5, "StudentT", 8, sd)
+    out = run(model, img, ev)
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_refinement_steps=2))
+    for k in iefvad_amd.OUTPUT_KEYS:
+        r = ref[k].numpy()
+        assert np.array_equal(np.isnan(out[k]), np.isnan(r)), k
+        fin = ~np.isnan(r)
+        assert np.abs(out[k][fin] - r[fin]).max() <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), k
+    assert np.isnan(out["logits"][1]).all() and np.isfinite(out["logits"][[0, 2]]).all()
+    assert np.isfinite(out["event_mu"]).all()          # the event branch never saw the inf
