@@ -257,31 +257,61 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
 
 
 class FeatureFilePipeline:
-    """Streaming front end for real feature files: worker threads read the image / event
-    `.npy` pairs (numpy releases the GIL while reading) and chunk them with `process_split`; the consumer
-    packs the chunks of consecutive videos into pinned host staging buffers and issues the H2D copies on
-    a side stream, so file I/O, PCIe and the forward of the previous batch overlap.  Order is preserved.
-    Semantics match the reference loader + test() prologue: dtype preserved from disk (dataset.py:37-38,
-    49-50), conditional nan_to_num (test.py:90-95), the all-zero trailing chunk of a len % 256 == 0 video is
-    dropped (its rows are sliced away by test.py:121)."""
+    """Streaming front end for real feature files.  The `.npy` headers are parsed first (shape
+    and dtype without touching the payload), the chunks of consecutive videos are laid out into batches of
+    >= `batch_chunks` chunks, and worker threads then read() each video's image / event payload STRAIGHT into its
+    slot of a pinned host staging buffer (one copy, GIL released, in parallel); a finished batch goes to the
+    device on a side stream, so file I/O, PCIe and the forward of the previous batch overlap.  Order is preserved.
+    Semantics match the reference loader + test() prologue: dtype preserved from disk (dataset.py:37-38,49-50;
+    a batch mixing dtypes is widened to fp32, which `.to(torch.float)` does anyway), conditional nan_to_num
+    (test.py:90-95), and the all-zero trailing chunk of a len % 256 == 0 video is dropped (its rows are sliced
+    away by test.py:121)."""
 
     def __init__(self, paths: Sequence[str], labels: Sequence[str], clip_dim: int, event_dir: str, device,
-                 batch_chunks: int = 256, workers: int = 8, prefetch: int = 32):
+                 batch_chunks: int = 64, workers: int = 2, prefetch: int = 2):
         self.paths, self.labels = list(paths), list(labels)
         self.clip_dim, self.event_dir, self.device = clip_dim, event_dir, torch.device(device)
-        self.batch_chunks, self.workers, self.prefetch = batch_chunks, workers, prefetch
+        self.batch_chunks, self.workers, self.prefetch = batch_chunks, workers, max(1, prefetch)
 
-    def _load(self, idx):
-        # memory-mapped read: the only copy of the payload is page cache -> pinned staging buffer (made by the consumer)
+    @staticmethod
+    def _header(path):
+        """(shape, dtype, payload offset) of a .npy file without touching the payload."""
+        with open(path, 'rb') as f:
+            ver = np.lib.format.read_magic(f)
+            rd = np.lib.format.read_array_header_1_0 if ver == (1, 0) else np.lib.format.read_array_header_2_0
+            shape, fortran, dtype = rd(f)
+            if fortran or len(shape) != 2:
+                raise ValueError(f"{path}: expected a C-ordered [len, D] array")
+            return shape, dtype, f.tell()
+
+    def _open(self, idx):
         p = self.paths[idx]
-        img = np.load(p, mmap_mode='r')
-        ev = np.load(p.replace('rgb', self.event_dir), mmap_mode='r')
-        n = int(img.shape[0])
-        if np.isnan(img).any():
-            img = np.nan_to_num(img, nan=0.0)
-        if np.isnan(ev).any():
-            ev = np.nan_to_num(ev, nan=0.0)
-        return idx, img, ev, n
+        pe = p.replace('rgb', self.event_dir)
+        return (p,) + self._header(p), (pe,) + self._header(pe)
+
+    @staticmethod
+    def _fill(dst: np.ndarray, src):
+        """One read() of the payload from the page cache straight into the pinned staging rows (no intermediate
+        array, no page faults of a memory map); a dtype mismatch (mixed-dtype batch) goes through a temporary."""
+        path, shape, dtype, offset = src
+        with open(path, 'rb', buffering=0) as f:
+            f.seek(offset)
+            if dtype == dst.dtype:
+                got = f.readinto(memoryview(dst.reshape(-1).view(np.uint8)))
+                if got != dst.nbytes:
+                    raise IOError(f"{path}: short read ({got} of {dst.nbytes} bytes)")
+            else:
+                tmp = np.fromfile(f, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+                np.copyto(dst, tmp, casting='unsafe')
+        if np.issubdtype(dst.dtype, np.floating) and np.isnan(dst).any():
+            # conditional nan_to_num (test.py:90-95): NaN -> 0, +-inf -> the SOURCE dtype's max / min
+            fi = np.finfo(dtype)
+            np.nan_to_num(dst, copy=False, nan=0.0, posinf=float(fi.max), neginf=float(fi.min))
+
+    @classmethod
+    def _fill_many(cls, jobs):
+        for dst, src in jobs:
+            cls._fill(dst, src)
 
     def batches(self):
         """Yields (img [B,T,D] device tensor, ev, [(video index, n snippets, n chunks), ...])."""
@@ -290,58 +320,67 @@ class FeatureFilePipeline:
         copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         pin = self.device.type == 'cuda'
         with ThreadPoolExecutor(self.workers) as pool:
-            futs, nxt = [], 0
+            maps = list(pool.map(self._open, range(len(self.paths))))      # headers only
+            plans, cur, cur_chunks = [], [], 0
+            for idx, (mi, _) in enumerate(maps):
+                n = int(mi[1][0])
+                nch = (n // T + (1 if n % T else 0)) if n >= T else 1
+                cur.append((idx, n, nch))
+                cur_chunks += nch
+                if cur_chunks >= self.batch_chunks:
+                    plans.append(cur)
+                    cur, cur_chunks = [], 0
+            if cur:
+                plans.append(cur)
 
-            def top_up():
-                nonlocal nxt
-                while nxt < len(self.paths) and len(futs) < self.prefetch:
-                    futs.append(pool.submit(self._load, nxt))
-                    nxt += 1
-
-            top_up()
-            pend, pend_chunks = [], 0
-
-            def emit():
-                nonlocal pend, pend_chunks
-                dt = np.float32 if len({a[1].dtype for a in pend}) > 1 else pend[0][1].dtype
-                D = pend[0][1].shape[1]
+            def start(plan):
+                dts = {maps[i][0][2] for i, _, _ in plan} | {maps[i][1][2] for i, _, _ in plan}
+                dt = np.dtype(np.float32) if len(dts) > 1 else next(iter(dts))
+                D = int(maps[plan[0][0]][0][1][1])
+                nchunks = sum(nch for _, _, nch in plan)
                 tdt = torch.from_numpy(np.zeros(0, dt)).dtype
-                hi = torch.zeros(pend_chunks, T, D, dtype=tdt, pin_memory=pin)
-                he = torch.zeros(pend_chunks, T, D, dtype=tdt, pin_memory=pin)
-                meta, off = [], 0
-                for idx, img, ev, n in pend:
-                    nch = n // T + (1 if n % T else 0) if n >= T else 1
-                    hi[off:off + nch].reshape(-1, D).numpy()[:n] = img
-                    he[off:off + nch].reshape(-1, D).numpy()[:n] = ev
-                    meta.append((idx, n, nch))
+                hi = torch.empty(nchunks, T, D, dtype=tdt, pin_memory=pin)
+                he = torch.empty(nchunks, T, D, dtype=tdt, pin_memory=pin)
+                ni, ne = hi.numpy().reshape(-1, D), he.numpy().reshape(-1, D)
+                futs, off = [], 0
+                jobs = []
+                for idx, n, nch in plan:
+                    jobs.append((ni[off * T:off * T + n], maps[idx][0]))
+                    jobs.append((ne[off * T:off * T + n], maps[idx][1]))
+                    ni[off * T + n:(off + nch) * T] = 0          # zero padding of the video's last chunk only
+                    ne[off * T + n:(off + nch) * T] = 0
                     off += nch
+                # a few coarse tasks per batch: a page-cache read() runs at ~12 GB/s on one thread, so the Python
+                # per-task overhead (and the GIL) of hundreds of tiny tasks would dominate
+                nt = max(1, min(self.workers, len(jobs)))
+                for w in range(nt):
+                    futs.append(pool.submit(self._fill_many, jobs[w::nt]))
+                return hi, he, futs, plan
+
+            inflight = [start(p) for p in plans[:self.prefetch]]
+            nxt = len(inflight)
+            while inflight:
+                hi, he, futs, plan = inflight.pop(0)
+                for f in futs:
+                    f.result()
+                if nxt < len(plans):
+                    inflight.append(start(plans[nxt]))
+                    nxt += 1
                 if copy_stream is not None:
                     with torch.cuda.stream(copy_stream):
                         di = hi.to(self.device, non_blocking=True)
                         de = he.to(self.device, non_blocking=True)
-                    ev_done = torch.cuda.Event()
-                    ev_done.record(copy_stream)
-                    torch.cuda.current_stream(self.device).wait_event(ev_done)
+                    done = torch.cuda.Event()
+                    done.record(copy_stream)
+                    torch.cuda.current_stream(self.device).wait_event(done)
                     di.record_stream(torch.cuda.current_stream(self.device))
                     de.record_stream(torch.cuda.current_stream(self.device))
                 else:
                     di, de = hi, he
-                pend, pend_chunks = [], 0
-                return di, de, meta
-
-            while futs:
-                idx, img, ev, n = futs.pop(0).result()
-                top_up()
-                nch = (n // T + (1 if n % T else 0)) if n >= T else 1
-                pend.append((idx, img, ev, n))
-                pend_chunks += nch
-                if pend_chunks >= self.batch_chunks:
-                    yield emit()
-            if pend:
-                yield emit()
+                yield di, de, plan
 
 
-def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch_chunks: int = 256, workers: int = 8,
+def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch_chunks: int = 64, workers: int = 2,
                    device_metrics: bool = True, verbose: bool = False):
     """End-to-end evaluation from a `path,label` CSV of feature files: streaming loader -> batched forward ->
     ordered scores -> AUC / AP (on the device when `device_metrics`).  Returns a dict with the metrics, the
