@@ -74,10 +74,14 @@ struct iefvad_handle {
     bf16_t* ref_w2b[IEFVAD_MAX_STEPS];
 };
 
-static const int kDefaultMicroBatch = 256;   // chunks per internal pass (65536 rows)
+// chunks per internal pass: 256 (65,536 rows, 2.8 GB of workspace) in fp32 mode; the bf16 kernels are ~100 us
+// each at that size and gain another 7 % from 4x longer launches (1024 chunks, 11 GB of workspace)
+static const int kDefaultMicroBatchF32 = 256;
+static const int kDefaultMicroBatchBF16 = 1024;
 
 static int micro_batch(const iefvad_handle* h) {
-    return h->cfg.micro_batch > 0 ? h->cfg.micro_batch : kDefaultMicroBatch;
+    if (h->cfg.micro_batch > 0) return h->cfg.micro_batch;
+    return h->cfg.compute == IEFVAD_COMPUTE_BF16 ? kDefaultMicroBatchBF16 : kDefaultMicroBatchF32;
 }
 
 extern "C" int iefvad_abi_version(void) { return IEFVAD_ABI_VERSION; }
