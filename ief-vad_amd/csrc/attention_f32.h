@@ -5,7 +5,8 @@
 // ALL 256 keys -- padding_mask is accepted and ignored by the reference (imf_vad.py:40-44), so zero
 // padded rows are attended to, and this kernel does the same.
 //
-// Q arrives pre-scaled by 1/sqrt(96) from the in_proj epilogue.  The kernel computes the TRANSPOSED score tile
+// Q arrives pre-scaled by log2(e)/sqrt(96) from the in_proj epilogue, so the softmax is exp2(s - max) on
+// v_exp_f32 (1 ulp; the scale folds into the one fp32 multiply q already gets).  The kernel computes the TRANSPOSED score tile
 // S^T = K Q^T, so that in the 32x32 accumulator the lane index is the query and the 16 registers
 // are keys: the whole softmax row of a query lives in one lane pair (lanes q and q+32), needs no
 // LDS, and the probabilities are already laid out as the A operand of the P V product
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs a
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = expf(st[kt][r] - mx);
+                        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);   // scores arrive in log2 units
                         st[kt][r] = p;
                         sum += p;
                     }

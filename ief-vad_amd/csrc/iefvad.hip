@@ -441,8 +441,8 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             Proj p;
             memset(&p, 0, sizeof(p));
             p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
-            // q is pre-scaled for the softmax: 1/sqrt(96) (fp32, exp) or log2(e)/sqrt(96) (bf16 mode, exp2)
-            p.alpha = bf ? qscale * 1.4426950408889634f : qscale;
+            // q is pre-scaled for the softmax by log2(e)/sqrt(96): both attention kernels use exp2
+            p.alpha = qscale * 1.4426950408889634f;
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l];
                 p.bias[m] = h->in_b[m][l];
