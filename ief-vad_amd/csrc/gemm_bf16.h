@@ -302,6 +302,9 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     GB2_STAGE(1, s1)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef GB2_CLOCK_DIAG
+    const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int kt = 0;
     for (; kt + 2 < nk; ++kt) {
         GB2_STAGE(kt + 2, s2)                         // s2 held tile kt-1: every wave passed the barrier after reading it
@@ -316,6 +319,13 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     GB2_COMPUTE(s1)                                   // tile nk-1
+#ifdef GB2_CLOCK_DIAG
+    if (threadIdx.x == 0 && P.C2) {   // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        unsigned long long* dg = (unsigned long long*)P.C2 + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dg[0] = __builtin_amdgcn_s_memtime() - dg_c0;
+        dg[1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+    }
+#endif
 #undef GB2_COMPUTE
 #undef GB2_STAGE
 #undef GLDS16

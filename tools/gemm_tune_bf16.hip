@@ -74,5 +74,20 @@ int main(int argc, char** argv) {
                    fl / t[v][rounds / 2] * 1e-9, fl / t[v][0] * 1e-9, fl / t[v][rounds - 1] * 1e-9);
         }
     }
+#ifdef GB2_CLOCK_DIAG
+    {   // in-kernel clock of the v2 main loop under sustained load (>= 1 s of back-to-back launches first)
+        unsigned long long* dclk; CK(hipMalloc(&dclk, 16 * 2048 * 4));
+        GemmBArgs g; memset(&g, 0, sizeof(g));
+        g.M = M; g.N = 768; g.K = K; g.lda = K; g.ldc = 768; g.epi = EPI_BIAS;
+        g.p[0].A = A; g.p[0].W = W; g.p[0].bias = bias; g.p[0].C = nullptr; g.p[0].Cb = Cb; g.p[0].C2 = (float*)dclk; g.p[1] = g.p[0];
+        dim3 grid((M / GB2_BM) * (768 / GB2_BN), 1, 1);
+        for (int it = 0; it < 10000; ++it) hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> c(2 * grid.x); CK(hipMemcpy(c.data(), dclk, c.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> ghz; for (size_t b = 0; b < grid.x; ++b) ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        printf("bf16 v2 main loop in-kernel clock: median %.3f GHz (min %.3f max %.3f), loop cycles median %llu\n", ghz[ghz.size() / 2], ghz.front(), ghz.back(), c[2 * (grid.x / 2)]);
+    }
+#endif
     return 0;
 }
