@@ -1,0 +1,98 @@
+// Torch-free consumer of libiefvad.so: includes only include/iefvad.h and the HIP runtime API.
+//   abi_driver <blob.bin> <B> <L> <K> <out_logits.bin> [compute]
+// blob.bin: float32 stream written by tests/test_gpu_cabi_driver.py: every state_dict tensor in the order of
+// iefvad_amd.synth.state_dict_keys(L, K), 3 floats of padding, then img [B,256,768], then ev [B,256,768].
+// Writes B*256 fp32 logits.  Exit code 0 on success; any ABI error prints iefvad_last_error().
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "iefvad.h"
+
+#define HIPCK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 2; } } while (0)
+#define ABICK(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, iefvad_last_error()); return 3; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s blob B L K out [compute]\n", argv[0]); return 1; }
+    const int B = atoi(argv[2]), L = atoi(argv[3]), K = atoi(argv[4]);
+    const int compute = argc > 6 ? atoi(argv[6]) : IEFVAD_COMPUTE_F32;
+    const size_t D = 768, T = 256, DD = D * D;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("blob"); return 1; }
+    fseek(f, 0, SEEK_END);
+    const size_t nfloat = (size_t)ftell(f) / 4;
+    fseek(f, 0, SEEK_SET);
+    std::vector<float> host(nfloat);
+    if (fread(host.data(), 4, nfloat, f) != nfloat) { fprintf(stderr, "short read\n"); return 1; }
+    fclose(f);
+    const size_t nweights = 2 * (size_t)L * (3 * DD + 3 * D + DD + D + 2 * D) + 4 * D + 4 * (DD + D) + (size_t)K * 2 * (DD + D) + D + 1 + 3;
+    if (nfloat != nweights + 2 * (size_t)B * T * D) { fprintf(stderr, "blob has %zu floats, expected %zu\n", nfloat, nweights + 2 * (size_t)B * T * D); return 1; }
+    float* dev = nullptr;
+    HIPCK(hipMalloc((void**)&dev, nfloat * 4));
+    HIPCK(hipMemcpy(dev, host.data(), nfloat * 4, hipMemcpyHostToDevice));
+
+    // carve the blob exactly in state_dict registration order
+    iefvad_weights w;
+    memset(&w, 0, sizeof(w));
+    const float* p = dev;
+    auto take = [&](size_t n) { const float* q = p; p += n; return q; };
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l < L; ++l) {
+            w.in_proj_w[m][l] = take(3 * DD); w.in_proj_b[m][l] = take(3 * D);
+            w.out_proj_w[m][l] = take(DD); w.out_proj_b[m][l] = take(D);
+        }
+        for (int l = 0; l < L; ++l) { w.norm_w[m][l] = take(D); w.norm_b[m][l] = take(D); }
+    }
+    for (int m = 0; m < 2; ++m) { w.whiten_w[m] = take(D); w.whiten_b[m] = take(D); }
+    w.mu_w[0] = take(DD); w.mu_b[0] = take(D);           // image_mu
+    w.mu_w[1] = take(DD); w.mu_b[1] = take(D);           // event_mu
+    w.logvar_w[0] = take(DD); w.logvar_b[0] = take(D);   // image_logvar
+    w.logvar_w[1] = take(DD); w.logvar_b[1] = take(D);   // event_logvar
+    for (int k = 0; k < K; ++k) {
+        w.ref_w1[k] = take(DD); w.ref_b1[k] = take(D);
+        w.ref_w2[k] = take(DD); w.ref_b2[k] = take(D);
+    }
+    w.cls_w = take(D); w.cls_b = take(1);
+    (void)take(3);   // pad: the feature blocks must be 16-byte aligned (the forward checks it)
+    const float* img = take((size_t)B * T * D);
+    const float* ev = take((size_t)B * T * D);
+
+    iefvad_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = IEFVAD_ABI_VERSION; cfg.embed_dim = 768; cfg.seq_len = 256; cfg.num_heads = 8;
+    cfg.num_layers = L; cfg.num_steps = K; cfg.noise_model = IEFVAD_NOISE_STUDENT_T; cfg.compute = compute;
+    cfg.lambda_ref = 0.5f; cfg.nu = 8.0f; cfg.epsilon = 1e-8f; cfg.micro_batch = 0;
+    iefvad_handle* h = nullptr;
+    ABICK(iefvad_create(&cfg, &h));
+    hipStream_t stream;
+    HIPCK(hipStreamCreate(&stream));
+    ABICK(iefvad_set_weights(h, &w, stream));
+    const size_t wsb = iefvad_workspace_bytes(h, B);
+    void* ws = nullptr;
+    HIPCK(hipMalloc(&ws, wsb));
+    float* logits = nullptr;
+    HIPCK(hipMalloc((void**)&logits, (size_t)B * T * 4));
+    iefvad_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.logits = logits;
+    ABICK(iefvad_forward(h, img, ev, IEFVAD_IN_F32, B, ws, wsb, &out, stream));
+    iefvad_stage_times st;
+    ABICK(iefvad_forward_timed(h, img, ev, IEFVAD_IN_F32, B, ws, wsb, &out, stream, &st));
+    HIPCK(hipStreamSynchronize(stream));
+    std::vector<float> hl((size_t)B * T);
+    HIPCK(hipMemcpy(hl.data(), logits, hl.size() * 4, hipMemcpyDeviceToHost));
+    FILE* o = fopen(argv[5], "wb");
+    if (!o || fwrite(hl.data(), 4, hl.size(), o) != hl.size()) { fprintf(stderr, "cannot write output\n"); return 1; }
+    fclose(o);
+    // error path: a too-small workspace must be refused with a message, not crash
+    if (iefvad_forward(h, img, ev, IEFVAD_IN_F32, B, ws, 16, &out, stream) == 0 || strstr(iefvad_last_error(), "workspace") == nullptr) {
+        fprintf(stderr, "small workspace was not refused\n");
+        return 4;
+    }
+    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches\n", B, L, K, st.total_ms, st.gemm_launches);
+    iefvad_destroy(h);
+    (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);
+    return 0;
+}

@@ -1,0 +1,49 @@
+"""The C ABI used WITHOUT Python or torch on the calling side: tests/cabi/abi_driver.cpp includes only
+include/iefvad.h and the HIP runtime, loads seeded weights + inputs from a flat fp32 blob, runs the forward and
+writes the logits, which must equal the ctypes/torch path's bit for bit."""
+import argparse
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_torch_free_c_driver_matches_python_path(tmp_path):
+    L, K, B = 2, 3, 2
+    exe = tmp_path / "abi_driver"
+    libdir = os.path.dirname(iefvad_amd.lib.LIB_PATH)
+    # plain g++: the driver is host-only C++ (HIP runtime API + the C header), no device code, no torch
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "abi_driver.cpp"),
+                           "-L", libdir, "-liefvad", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    sd = synth.make_state_dict(91, 768, L, K)
+    img, ev = synth.make_inputs(92, B)
+    blob = tmp_path / "blob.bin"
+    with open(blob, "wb") as f:
+        for key, _, _ in synth.state_dict_keys(L, K):
+            f.write(sd[key].numpy().astype(np.float32).tobytes())
+        f.write(np.zeros(3, np.float32).tobytes())      # keep the feature blocks 16-byte aligned
+        f.write(img.tobytes())
+        f.write(ev.tobytes())
+    out = tmp_path / "logits.bin"
+    r = subprocess.run([str(exe), str(blob), str(B), str(L), str(K), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_driver OK" in r.stdout
+    got = np.fromfile(out, dtype=np.float32).reshape(B, 256)
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5,
+                              noise_model="StudentT", nu=8)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, outputs="scores")
+    m.load_state_dict(sd)
+    m = m.to("cuda:0").eval()
+    with torch.no_grad():
+        ref = m(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)["logits"].cpu().numpy()
+    assert np.array_equal(got, ref.reshape(B, 256))
