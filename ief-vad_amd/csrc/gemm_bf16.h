@@ -220,8 +220,17 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // One body, two element types: F32 = false -> bf16 operands (32 elements per 64-byte row, v_mfma_f32_32x32x16_bf16);
 // F32 = true -> fp32 operands (16 elements per row; each 16-byte fragment feeds four v_mfma_f32_32x32x2_f32, lane
 // half h taking k = 8s+4h..+3 exactly as iefvad_gemm_f32_kernel does, so the fp32 results are bit-identical to it).
-template <bool F32>
+// MODE 2 = bf16 operands on v_mfma_f32_16x16x32_bf16: one 16-byte fragment (lane (r = lane & 15, q = lane >> 4) holds
+// row r, k = 8q .. 8q+7) covers the whole 32-wide k-tile, so a tile is 4 A + 8 B fragment reads feeding 32 MFMAs of
+// 16 cycles -- the same reads, FLOPs and cycles as MODE 0 -- but the chip holds a higher clock on this shape
+// (MI355X_MICROARCH.md, DVFS item 7; measured here: see DESIGN.md).  Its LDS image uses the chunk swizzle
+// G[(row>>2)&3], G = {2,0,1,3}, which makes the (row, q) access pattern of the 16x16 fragment conflict-free.
+enum { T256_BF16_32 = 0, T256_F32 = 1, T256_BF16_16 = 2 };
+
+template <int MODE>
 __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* smem) {
+    constexpr bool F32 = (MODE == T256_F32);
+    constexpr bool MF16 = (MODE == T256_BF16_16);
     constexpr int EB = F32 ? 4 : 2;                     // bytes per operand element
     constexpr int BKE = 64 / EB;                        // elements per k-tile row (64 bytes)
     const GemmBProblem& P = args.p[blockIdx.z];
@@ -238,7 +247,8 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 
     // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3
     const int srow = t >> 2, sch = t & 3;
-    const int ssw = (srow >> 2) & 3;
+    auto swz = [](int row) { const int x = (row >> 2) & 3; return MF16 ? ((0xD2 >> (2 * x)) & 3) : x; };
+    const int ssw = swz(srow);                          // rows srow + 64 j share it
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * EB), 0,
                                                        (int)((GB2_BM - 1) * lda + K) * EB, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * EB), 0,
@@ -263,17 +273,39 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     for (int x = 0; x < 2; ++x) aoff[x] = (wr * 64 + x * 32 + i) * 16;
 #pragma unroll
     for (int x = 0; x < 4; ++x) boff[x] = GB2_BM * 16 + (wc * 128 + x * 32 + i) * 16;
+    // 16x16x32 fragments: lane (r16, q16) reads row (16 x + r16), chunk q16 (swizzled) of the A / W image
+    const int r16 = lane & 15, q16 = lane >> 4;
+    const int f16 = (q16 ^ swz(r16)) << 2;              // rows 16 x + r16 share (row>>2)&3 with r16
+    const int a16 = (wr * 64 + r16) * 16 + f16;
+    const int b16 = GB2_BM * 16 + (wc * 128 + r16) * 16 + f16;
 
     f32x16 acc[2][4];
+    f32x4 acc16[4][8];
+    if constexpr (MF16) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 8; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
 
 #define GB2_COMPUTE(slotbase)                                                                               \
-    {                                                                                                       \
+    if constexpr (MF16) {                                                                                   \
+        const float* S = smem + (slotbase);                                                                 \
+        f32x4 ga[4], gb[8];                                                                                 \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) ga[x] = *(const f32x4*)(S + a16 + x * 16 * 16);       \
+        _Pragma("unroll") for (int x = 0; x < 8; ++x) gb[x] = *(const f32x4*)(S + b16 + x * 16 * 16);       \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                       \
+            _Pragma("unroll") for (int b = 0; b < 8; ++b)                                                   \
+                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
+                    __builtin_bit_cast(bf16x8, ga[a]), __builtin_bit_cast(bf16x8, gb[b]), acc16[a][b], 0, 0, 0); \
+    } else {                                                                                                \
         const float* S = smem + (slotbase);                                                                 \
         f32x4 fa[2][2], fb[2][4];   /* 16-byte fragments: 4 fp32 or 8 bf16 */                                \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
@@ -355,11 +387,22 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 #pragma unroll
             for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
         }
+        if constexpr (MF16) {
+            // 16x16 accumulator map: col = lane & 15, row = 4 (lane >> 4) + reg; this pass takes row sub-tiles 2a, 2a+1
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        E[(x * 16 + 4 * q16 + r) * GB2_EPI_LD + b * 16 + r16] = acc16[2 * a + x][b][r];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
+        }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             f32x4 v = *(const f32x4*)(E + (rq + 2 * u) * GB2_EPI_LD + 4 * cq);
@@ -382,13 +425,20 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     }
 }
 
+// the bf16 projection kernel: 16x16x32 MFMA shape (+4..9 % over the 32x32x16 shape at equal cycles: higher clock)
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_t256_body<false>(args, smem);
+    gemm_t256_body<T256_BF16_16>(args, smem);
+}
+
+// the same kernel on the 32x32x16 shape, kept for A/B runs in tools/gemm_tune_bf16
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_m32_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_t256_body<T256_BF16_32>(args, smem);
 }
 
 // fp32 operands on the same 128x256 / 3-slot-ring structure (A and W of GemmBProblem then point to fp32 data)
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_t256_kernel(GemmBArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_t256_body<true>(args, smem);
+    gemm_t256_body<T256_F32>(args, smem);
 }

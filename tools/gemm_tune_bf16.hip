@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <math.h>
 #include "../ief-vad_amd/csrc/gemm_bf16.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -20,6 +21,9 @@ static float time_variant(const Variant& v, GemmBArgs g, int iters) {
     CK(hipEventRecord(e0));
     for (int it = 0; it < iters; ++it) {
         if (v.kind == 2) {
+            dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_m32_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        } else if (v.kind == 3) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
         } else {
@@ -47,10 +51,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(W, h.data(), (size_t)2304 * K * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, 2304 * 4)); CK(hipMemset(C, 0, (size_t)M * 2304 * 4));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
-    const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"v2 bias  C32", 2, EPI_BIAS, 1, true, false},
-                          {"v2 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"v2 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
-                          {"v2 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"v2 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
-                          {"v2 bias  C32 z=2", 2, EPI_BIAS, 2, true, false}, {"v2 none (no stores)", 2, EPI_BIAS, 1, false, false}};
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_m32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
+    const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"m32 bias  C32", 2, EPI_BIAS, 1, true, false},
+                          {"m32 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"m32 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
+                          {"m32 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"m32 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
+                          {"m32 bias  C32 z=2", 2, EPI_BIAS, 2, true, false}, {"m32 none (no stores)", 2, EPI_BIAS, 1, false, false},
+                          {"m16 bias  C32", 3, EPI_BIAS, 1, true, false}, {"m16 relu  C16 only", 3, EPI_BIAS_RELU, 1, false, true},
+                          {"m16 refine C32+C16", 3, EPI_REFINE, 1, true, true}, {"m16 bias  C32 z=2", 3, EPI_BIAS, 2, true, false},
+                          {"m16 none (no stores)", 3, EPI_BIAS, 1, false, false}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int ni = 0; ni < 2; ++ni) {
         GemmBArgs g; memset(&g, 0, sizeof(g));
@@ -62,7 +70,11 @@ int main(int argc, char** argv) {
             CK(hipMemset(C, 0, c1.size() * 4));
             time_variant(vs[1], g, 1); CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
             size_t bad = 0; for (size_t q = 0; q < c1.size(); ++q) bad += (c1[q] != c2[q]);
-            printf("N=%d: v2 vs v1: %zu mismatching elements of %zu\n", g.N, bad, c1.size());
+            printf("N=%d: m32 vs v1: %zu mismatching elements of %zu\n", g.N, bad, c1.size());
+            CK(hipMemset(C, 0, c1.size() * 4));
+            time_variant(vs[8], g, 1); CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t q = 0; q < c1.size(); ++q) { double d = fabs((double)c1[q] - c2[q]); if (d > md) md = d; }
+            printf("N=%d: m16 vs v1: max abs diff %.3g (different fp32 summation order inside a k-tile)\n", g.N, md);
         }
         std::vector<std::vector<float>> t(nv);
         for (int r = 0; r < rounds; ++r)
