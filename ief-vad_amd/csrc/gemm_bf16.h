@@ -1,17 +1,24 @@
-// Dense projection GEMM, bf16 operands / fp32 accumulation (throughput mode: "bf16 projections with fp32
-// fusion state", BASELINE config 3).  Same contraction and epilogues as gemm_f32.h:
+// Dense projection GEMMs on the 128 x 256 / 3-slot-ring structure, and the bf16 operand path.
 //
-//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] ),  A and W bf16, K-contiguous; bias, residual and C fp32;
-//   optionally a bf16 copy Cb of the result (the A operand of the next projection).
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] ),  A and W K-contiguous; bias, residual and C fp32;
+//   optionally a bf16 copy Cb of the result (the A operand of the next bf16 projection).
 //
-// v_mfma_f32_32x32x16_bf16: lane (i, h) supplies A[i][k = 8h + j], B[k = 8h + j][i'] (j = 0..7) as one
-// 16-byte fragment = one ds_read_b128; the accumulator map is the one of the fp32 kernel.
-// Tiling: 128x128 block tile, BK = 64 bf16 (128-byte rows: the LDS image, its XOR swizzle, the LDS-DMA
-// staging pattern and the fragment addressing are byte-for-byte those of the fp32 kernel), 4 waves as
-// 2x2 of 64x64, double-buffered 64 KB LDS -> 2 blocks per CU.
-// The epilogue goes through LDS: each wave parks its 64x64 fp32 tile in a private, padded LDS image and
-// re-reads it row-wise, so global stores (and the residual / bias loads) are 16 bytes per lane and whole
-// 256-byte row segments per 16 lanes instead of 4-byte (2-byte for the bf16 copy) column-strided accesses.
+// Kernels in this file
+//   iefvad_gemm_f32_t256_kernel   fp32 operands, v_mfma_f32_32x32x2_f32 -- the throughput kernel of the default
+//                                 (parity) mode; bit-identical to the 128x128 and 64x64 kernels of gemm_f32.h
+//   iefvad_gemm_bf16_kernel       bf16 operands, v_mfma_f32_16x16x32_bf16 -- throughput mode ("bf16 projections with
+//                                 fp32 fusion state", BASELINE config 3)
+//   iefvad_gemm_bf16_m32_kernel   the same on v_mfma_f32_32x32x16_bf16 (A/B runs)
+//   iefvad_gemm_bf16_v1_kernel    128x128 double-buffer fallback for shapes the ring kernel does not take
+// All three ring kernels are one template body (gemm_t256_body): same LDS image, LDS-DMA staging, ring protocol and
+// LDS-staged epilogue; only the fragment -> MFMA step differs.
+//
+// v1 (below): 128x128 block tile, BK = 64 bf16 (128-byte rows: the LDS image, its XOR swizzle, the LDS-DMA staging
+// pattern and the fragment addressing are byte-for-byte those of iefvad_gemm_f32_kernel), 4 waves as 2x2 of 64x64,
+// v_mfma_f32_32x32x16_bf16 (lane (i, h) supplies A[i][k = 8h + j], B[k = 8h + j][i'], j = 0..7, as one 16-byte
+// fragment), double-buffered 64 KB LDS -> 2 blocks per CU.  Its epilogue goes through LDS: each wave parks its
+// 64x64 fp32 tile in a private, padded image and re-reads it row-wise, so global stores (and the residual / bias
+// loads) are 16 bytes per lane and whole 256-byte row segments per 16 lanes.
 #pragma once
 #include "common.h"
 #include "gemm_f32.h"
@@ -201,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 
 
 // ------------------------------------------------------------------------------------------------------------
-// v2: 128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (8 accumulators), BK = 32 bf16 (64-byte rows), 3-slot
+// Ring structure: 128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (8 accumulators), 64-byte k-tile rows (32 bf16 /
+// 16 fp32), 3-slot
 // LDS ring (3 x 24 KB = 72 KB -> 2 blocks per CU) filled by LDS-DMA two k-tiles ahead with a COUNTED
 // s_waitcnt vmcnt(6): the k-tile of this GEMM is only 16 MFMAs (512 cycles) per wave, shorter than an L2 round
 // trip, so a one-tile-ahead double buffer (v1) exposes the DMA latency every tile; two tiles of distance
