@@ -217,6 +217,14 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // MFMAs (v1: 8) and 25 % fewer staged bytes per FLOP.  LDS image per slot: [384 rows][64 B] (A rows then W
 // rows), 16-byte chunk index XOR (row>>2)&3 (conflict-free ds_read_b128).  Same k order as v1: bit-identical.
 // ------------------------------------------------------------------------------------------------------------
+// raw s_barrier (no vmcnt(0): LDS-DMA of later tiles stays in flight across it) fenced for the COMPILER on both
+// sides: the intrinsic is IntrNoMem, so without the empty asm a later ds_read could legally be hoisted above it
+#define GB2_BARRIER()                       \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();       \
+        asm volatile("" ::: "memory");      \
+    } while (0)
 #define GB2_BM 128
 #define GB2_BN 256
 #define GB2_BK 32                                   // bf16 elements per k-tile
@@ -341,7 +349,7 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     GB2_STAGE(0, s0)
     GB2_STAGE(1, s1)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    GB2_BARRIER();
 #ifdef GB2_CLOCK_DIAG
     const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -351,13 +359,13 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
         GB2_COMPUTE(s0)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own DMAs of tile kt+1 landed; tile kt+2's six stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        GB2_BARRIER();
         const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
     }
     GB2_COMPUTE(s0)                                   // tile nk-2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    GB2_BARRIER();
     GB2_COMPUTE(s1)                                   // tile nk-1
 #ifdef GB2_CLOCK_DIAG
     if (threadIdx.x == 0 && P.C2) {   // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
@@ -370,7 +378,7 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 #undef GB2_STAGE
 #undef GLDS16
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // every wave is done with the ring: reuse it for the epilogue
+    GB2_BARRIER();                     // every wave is done with the ring: reuse it for the epilogue
 
     // ---- epilogue through LDS: the wave parks 32 rows x 128 columns at a time and re-reads them row-wise;
     // lane (rq = lane >> 5, cq = lane & 31) owns columns 4 cq .. 4 cq + 3 of rows rq + 2 u, u = 0..15.
