@@ -21,6 +21,7 @@
 struct AttnBArgs {
     const bf16_t* qkv[2];   // [N, 2304] bf16 per modality: q | k | v, head h at columns h*96
     bf16_t* out[2];         // [N, 768] bf16 per modality
+    int nchunks;            // chunks per modality in this launch
 };
 
 #define ATTB_KROW 104   // K image row length in bf16 elements (208 B = 13 x 16 B)
@@ -29,7 +30,10 @@ struct AttnBArgs {
 
 __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs args) {
     __shared__ __attribute__((aligned(16))) bf16_t kv[IEF_T * ATTB_KROW];
-    const int head = blockIdx.x, chunk = blockIdx.y, mod = blockIdx.z >> 1, qhalf = blockIdx.z & 1;
+    // grid (8 heads, 2 query halves, chunks x modalities): the two halves of a (chunk, head) are 8 apart in linear
+    // block order, i.e. dispatched back to back onto the SAME XCD (round-robin over 8), so the second half's K / V
+    // re-read hits that XCD's L2 instead of HBM
+    const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
     const bf16_t* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
     bf16_t* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
 

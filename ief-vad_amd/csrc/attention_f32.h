@@ -20,6 +20,7 @@ struct AttnArgs {
     const float* qkv[2];   // [N, 2304] per modality: q | k | v, head h at columns h*96
     float* out[2];         // [N, 768] per modality: concat over heads (fp32), or
     __bf16* outb[2];       // the same as bf16 when non-null (A operand of a bf16 out_proj)
+    int nchunks;           // chunks per modality in this launch
 };
 
 #define ATT_LDK 100
@@ -33,7 +34,10 @@ struct AttnArgs {
 // share a CU, so one workgroup's softmax and barriers hide under the other's matrix work.
 __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs args) {
     __shared__ __attribute__((aligned(16))) float kv[2 * ATT_TILE];
-    const int head = blockIdx.x, chunk = blockIdx.y, mod = blockIdx.z >> 1, qhalf = blockIdx.z & 1;
+    // grid (8 heads, 2 query halves, chunks x modalities): the two halves of a (chunk, head) are 8 apart in linear
+    // block order, i.e. dispatched back to back onto the SAME XCD (round-robin over 8), so the second half's K / V
+    // re-read hits that XCD's L2 instead of HBM
+    const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
     const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
     const size_t obase = (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
     float* out = args.out[mod] ? args.out[mod] + obase : nullptr;

@@ -80,7 +80,7 @@ static const int kDefaultMicroBatchF32 = 256;
 static const int kDefaultMicroBatchBF16 = 1024;
 
 static int micro_batch(const iefvad_handle* h) {
-    if (h->cfg.micro_batch > 0) return h->cfg.micro_batch;
+    if (h->cfg.micro_batch > 0) return h->cfg.micro_batch < 16384 ? h->cfg.micro_batch : 16384;   // attention grid.z = 2 x chunks
     return h->cfg.compute == IEFVAD_COMPUTE_BF16 ? kDefaultMicroBatchBF16 : kDefaultMicroBatchF32;
 }
 
@@ -454,12 +454,14 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             if (bf) {
                 AttnBArgs ab;
                 for (int m = 0; m < 2; ++m) { ab.qkv[m] = qkvb[m]; ab.out[m] = attb[m]; }
-                hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, nb, 4), dim3(256), 0, stream, ab);
+                ab.nchunks = nb;
+                hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
             } else {
                 AttnArgs aa;
                 memset(&aa, 0, sizeof(aa));
                 for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
-                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, nb, 4), dim3(256), 0, stream, aa);
+                aa.nchunks = nb;
+                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
             }
             tm.end(e);
             HIP_TRY(hipGetLastError());
