@@ -44,6 +44,7 @@ struct GemmBArgs {
     int epi;
     float alpha;
     int qcols;
+    int wplane;          // split kernel (gemm_split.h): bytes between the three bf16 planes of W
 };
 
 #define GEMMB_BK 64                 // bf16 elements per k-tile (128 bytes per row)
@@ -233,6 +234,78 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 #define GB2_EPI_LD 132                              // padded row (floats) of the per-wave epilogue image (32 x 128)
 #define GB2_LDS_BYTES (GB2_STAGES * GB2_SLOT * 4)   // 73,728 B
 
+// ---- epilogue of the 128 x 256 kernels, through LDS: each wave parks 32 rows x 128 columns of its 64 x 128 tile at a
+// time in a private padded image (the ring is dead by then; the caller has put a barrier after its last read) and
+// re-reads them row-wise, so bias / residual loads and stores are 16 bytes per lane and 512-byte row segments per
+// instruction.  MF16 selects the accumulator map (16x16 tiles in acc16, else 32x32 tiles in acc).
+template <bool MF16>
+__device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
+                                                   f32x16 (&acc)[2][4], f32x4 (&acc16)[4][8]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int r16 = lane & 15, q16 = lane >> 4;
+    // ---- epilogue through LDS: the wave parks 32 rows x 128 columns at a time and re-reads them row-wise;
+    // lane (rq = lane >> 5, cq = lane & 31) owns columns 4 cq .. 4 cq + 3 of rows rq + 2 u, u = 0..15.
+    const int epi = args.epi, ldc = args.ldc;
+    const float alpha = args.alpha;
+    const int rq = lane >> 5, cq = lane & 31;
+    const int ncol = n0 + wc * 128 + 4 * cq;
+    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
+    float* E = smem + wave * (32 * GB2_EPI_LD);       // 16.9 KB per wave
+    const f32x4 bv = *(const f32x4*)(P.bias + ncol);
+    float* C32 = P.C;
+    bf16_t* C16 = P.Cb;
+    int nn = ncol;
+    f32x4 scale = {1.f, 1.f, 1.f, 1.f};
+    if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
+    if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mrow = m0 + wr * 64 + a * 32 + rq;
+        f32x4 res[16];
+        if (has_resid) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
+        }
+        if constexpr (MF16) {
+            // 16x16 accumulator map: col = lane & 15, row = 4 (lane >> 4) + reg; this pass takes row sub-tiles 2a, 2a+1
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        E[(x * 16 + 4 * q16 + r) * GB2_EPI_LD + b * 16 + r16] = acc16[2 * a + x][b][r];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            f32x4 v = *(const f32x4*)(E + (rq + 2 * u) * GB2_EPI_LD + 4 * cq);
+            v = v + bv;
+            if (epi == EPI_QKV) v = v * scale;
+            else if (epi == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
+            } else if (epi == EPI_BIAS_RESID) v = v + res[u];
+            else if (epi == EPI_REFINE) v = res[u] - alpha * v;
+            const size_t o = (size_t)(mrow + 2 * u) * ldc + nn;
+            if (C32) *(f32x4*)(C32 + o) = v;
+            if (C16) {
+                bf16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                *(bf16x4*)(C16 + o) = w;
+            }
+        }
+    }
+}
+
 // One body, two element types: F32 = false -> bf16 operands (32 elements per 64-byte row, v_mfma_f32_32x32x16_bf16);
 // F32 = true -> fp32 operands (16 elements per row; each 16-byte fragment feeds four v_mfma_f32_32x32x2_f32, lane
 // half h taking k = 8s+4h..+3 exactly as iefvad_gemm_f32_kernel does, so the fp32 results are bit-identical to it).
@@ -380,65 +453,7 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     GB2_BARRIER();                     // every wave is done with the ring: reuse it for the epilogue
 
-    // ---- epilogue through LDS: the wave parks 32 rows x 128 columns at a time and re-reads them row-wise;
-    // lane (rq = lane >> 5, cq = lane & 31) owns columns 4 cq .. 4 cq + 3 of rows rq + 2 u, u = 0..15.
-    const int epi = args.epi, ldc = args.ldc;
-    const float alpha = args.alpha;
-    const int rq = lane >> 5, cq = lane & 31;
-    const int ncol = n0 + wc * 128 + 4 * cq;
-    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
-    float* E = smem + wave * (32 * GB2_EPI_LD);       // 16.9 KB per wave
-    const f32x4 bv = *(const f32x4*)(P.bias + ncol);
-    float* C32 = P.C;
-    bf16_t* C16 = P.Cb;
-    int nn = ncol;
-    f32x4 scale = {1.f, 1.f, 1.f, 1.f};
-    if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
-    if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int mrow = m0 + wr * 64 + a * 32 + rq;
-        f32x4 res[16];
-        if (has_resid) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
-        }
-        if constexpr (MF16) {
-            // 16x16 accumulator map: col = lane & 15, row = 4 (lane >> 4) + reg; this pass takes row sub-tiles 2a, 2a+1
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        E[(x * 16 + 4 * q16 + r) * GB2_EPI_LD + b * 16 + r16] = acc16[2 * a + x][b][r];
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            f32x4 v = *(const f32x4*)(E + (rq + 2 * u) * GB2_EPI_LD + 4 * cq);
-            v = v + bv;
-            if (epi == EPI_QKV) v = v * scale;
-            else if (epi == EPI_BIAS_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
-            } else if (epi == EPI_BIAS_RESID) v = v + res[u];
-            else if (epi == EPI_REFINE) v = res[u] - alpha * v;
-            const size_t o = (size_t)(mrow + 2 * u) * ldc + nn;
-            if (C32) *(f32x4*)(C32 + o) = v;
-            if (C16) {
-                bf16x4 w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
-                *(bf16x4*)(C16 + o) = w;
-            }
-        }
-    }
+    gemm_t256_epilogue<MF16>(args, P, smem, m0, n0, acc, acc16);
 }
 
 // the bf16 projection kernel: 16x16x32 MFMA shape (+4..9 % over the 32x32x16 shape at equal cycles: higher clock)

@@ -1,0 +1,315 @@
+// fp32-accurate projection GEMM on the bf16 matrix cores ("split" mode).
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] ),  A fp32 in HBM, W pre-split into three bf16 planes.
+//
+// MI355X multiplies bf16 16x faster than fp32 (2.5 PFLOP/s vs 157 TFLOP/s dense), so an fp32 product is cheaper as a
+// sum of bf16 products than as one v_mfma_f32_32x32x2_f32.  Every fp32 value is the exact sum of three bf16 values
+// obtained by round-to-nearest of the running remainder,
+//       x = x1 + x2 + x3,   x1 = bf16(x),  x2 = bf16(x - x1),  x3 = bf16(x - x1 - x2)
+// (8 + 9 + 9 significant bits >= 24; the subtractions are exact in fp32), and a bf16 x bf16 product is exact in the
+// fp32 accumulator.  Of the nine partial products the kernel keeps the six of relative size >= 2^-18,
+//       a3 w1 + a1 w3 + a2 w2 + a2 w1 + a1 w2 + a1 w1          (accumulated in that order, smallest first),
+// and drops a2 w3 + a3 w2 + a3 w3 <= 2^-26 |a w|: a quarter of the half-ulp an fp32 multiply itself rounds away.  What
+// is left is fp32 accumulation error, the same kind the fp32 MFMA path (and the reference's CPU GEMM) has; the parity
+// tests hold this mode to the SAME gates as the fp32 mode (tests/helpers.py TOL_*).  Non-finite inputs differ:
+// inf - inf in the remainder turns an inf operand into NaN (the fp32 path would propagate inf).
+//
+// Structure: 128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (32 accumulators of v_mfma_f32_16x16x32_bf16), k-tile
+// 32, ONE workgroup per CU (one wave per SIMD, ~330 of its 512 VGPR + AGPR): a k-tile is 192 MFMAs = 3072 cycles
+// per wave, long enough that a one-tile-ahead double buffer hides the LDS-DMA latency.
+//   LDS (128 KB): 2 x A slot [128 rows][128 B fp32]  +  2 x W slot 3 planes x [256 rows][64 B bf16]
+//   A is staged as fp32 (no extra HBM pass, producers keep writing fp32) and split in registers: the fragments of
+//   k-tile t+1 are read and split (11 VALU per element pair: v_cvt_pk_bf16_f32, shift / mask, exact subtractions) while
+//   the MFMAs of k-tile t run.  The A ring therefore runs one tile ahead of the W ring.
+//   W planes are split once, at iefvad_set_weights (iefvad_split_planes_kernel).
+//   LDS reads per wave and tile: 8 KB (A) + 24 KB (W) for 3072 MFMA cycles (the plain bf16 kernel: 12 KB per 512).
+// With one wave per SIMD nothing hides a stall of the wave's in-order instruction stream, so the issue ORDER is pinned
+// with sched_group_barrier: every non-MFMA instruction of a step (split VALU, LDS reads, LDS-DMA) sits between two
+// MFMAs -- an MFMA leaves 8 of its 16 issue cycles free (MI355X_MICROARCH.md, vector-instruction issue cost).
+// Swizzles (ds_read_b128 is served in the 16-lane groups of MI355X_MICROARCH.md, LDS): A image, 16-byte chunk index
+// XOR ((row>>1)&5): lane (r, q) reads chunks 2q, 2q+1 of row r, conflict-free; W image as in gemm_bf16.h (G[(row>>2)&3]).
+// Measured (tools/gemm_tune_split, M = 65,536): 200-207 TFLOP/s fp32-equivalent (1.2 PFLOP/s of bf16 MFMA) vs 137-141 for
+// the fp32 MFMA kernel; main loop 4150-4400 cycles per k-tile at 2.07-2.25 GHz (the chip trades clock for issue density),
+// prologue 5.5 k and epilogue 11.7 k cycles per block (all CUs store at once: one workgroup per CU).
+#pragma once
+#include "gemm_bf16.h"
+
+#ifndef GS_EXP_NODMA      // timing experiments of tools/gemm_tune_split (wrong results when set)
+#define GS_EXP_NODMA 0
+#endif
+#ifndef GS_EXP_NOSPLIT
+#define GS_EXP_NOSPLIT 0
+#endif
+#ifndef GS_EXP_NOBAR
+#define GS_EXP_NOBAR 0
+#endif
+#define GS_BM 128
+#define GS_BN 256
+#define GS_BK 32
+#define GS_A_SLOT (GS_BM * 32)                  // 4-byte units: 128 rows x 128 B
+#define GS_W_PLANE (GS_BN * 16)                 // 256 rows x 64 B
+#define GS_W_SLOT (3 * GS_W_PLANE)
+#define GS_W_BASE (2 * GS_A_SLOT)
+#define GS_LDS_BYTES ((2 * GS_A_SLOT + 2 * GS_W_SLOT) * 4)   // 131,072 B
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+// The split x = p1 + p2 + p3 (exact for finite x) of four fp32 values, one plane per call: the plane is bf16(r) of
+// the running remainder r (two packed dwords); `peel` then subtracts it from r exactly (bf16 -> fp32 is a shift or a
+// mask).  11 VALU instructions per element pair for the three planes.
+struct Split4 {
+    f32x4 r;
+    __device__ __forceinline__ void plane(unsigned& d0, unsigned& d1, bool peel) {
+        d0 = cvt_pk_bf16(r[0], r[1]);
+        d1 = cvt_pk_bf16(r[2], r[3]);
+        if (peel) {
+            r[0] -= __builtin_bit_cast(float, d0 << 16);
+            r[1] -= __builtin_bit_cast(float, d0 & 0xffff0000u);
+            r[2] -= __builtin_bit_cast(float, d1 << 16);
+            r[3] -= __builtin_bit_cast(float, d1 & 0xffff0000u);
+        }
+    }
+};
+
+// weights -> three bf16 planes (plane stride n elements), once per iefvad_set_weights
+__global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ planes, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        Split4 s;
+        s.r = *(const f32x4*)(src + i);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            unsigned d0, d1;
+            s.plane(d0, d1, p < 2);
+            *(uint2*)(planes + (size_t)p * n + i) = make_uint2(d0, d1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef GB2_CLOCK_DIAG
+    const unsigned long long dg_entry = __builtin_amdgcn_s_memtime();
+#endif
+    const GemmBProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GS_BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GS_BM, n0 = tn * GS_BN;
+    const int K = args.K, lda = args.lda;
+    const int wplane = args.wplane;                    // bytes between the bf16 planes of W
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, q16 = lane >> 4;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- staging (LDS-DMA, lane-linear 1 KB images; the swizzle is applied to the SOURCE chunk) ----
+    // A: one instruction = 8 rows x 128 B; wave w, instruction j -> rows 32 w + 8 j + (lane >> 3), chunk lane & 7
+    // W: one instruction = 16 rows x 64 B; wave w, plane p, instruction j -> rows 64 w + 16 j + (lane >> 2), chunk lane & 3
+    const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = 2 * wplane + (int)((GS_BN - 1) * K + K) * 2;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0, nrecA, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0, nrecW, 0x00020000);
+    const int arow = lane >> 3, achk = lane & 7;
+    int voA[2];                                        // row bit 3 = j & 1 enters the swizzle
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) voA[jj] = arow * lda * 4 + ((achk ^ (((arow >> 1) & 1) | (jj << 2))) << 4);
+    const int wrow = lane >> 2, wchk = lane & 3;
+    const int voW = wrow * K * 2 + ((wchk ^ ((0xD2 >> (2 * ((wrow >> 2) & 3))) & 3)) << 4);
+#define GLDS16(rs, vo, so, lp) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+#define GS_STAGE_A(tile, slot)                                                                                  \
+    {                                                                                                           \
+        float* Ad = smem + (slot) * GS_A_SLOT + uwave * 32 * 32;                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+            GLDS16(rsA, voA[j & 1], ((uwave * 32 + j * 8) * lda + (tile) * GS_BK) * 4, Ad + j * 8 * 32);        \
+    }
+#define GS_STAGE_W(tile, slot)                                                                                  \
+    {                                                                                                           \
+        float* Wd = smem + GS_W_BASE + (slot) * GS_W_SLOT + uwave * 64 * 16;                                    \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                GLDS16(rsW, voW, p * wplane + ((uwave * 64 + j * 16) * K + (tile) * GS_BK) * 2,                 \
+                       Wd + p * GS_W_PLANE + j * 16 * 16);                                                      \
+    }
+
+    // ---- fragment addresses (4-byte units) ----
+    const int swa = (r16 >> 1) & 5;
+    const int a_lo = (wr * 64 + r16) * 32 + (((2 * q16) ^ swa) << 2);
+    const int a_hi = (wr * 64 + r16) * 32 + (((2 * q16 + 1) ^ swa) << 2);
+    const int b_of = (wc * 128 + r16) * 16 + ((q16 ^ ((0xD2 >> (2 * ((r16 >> 2) & 3))) & 3)) << 2);
+
+    f32x4 acc16[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ap[4][3], an[4][3];                          // bf16 planes of the A fragments: current k-tile / next k-tile
+    auto mfma4 = [&](int b, int pa, const u32x4& wv) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[a][pa]),
+                                                                  __builtin_bit_cast(bf16x8, wv), acc16[a][b], 0, 0, 0);
+    };
+    // half `hf` (k = 8q + 4 (hf & 1) .. + 3) of row-tile (hf >> 1) of the NEXT k-tile: fp32 fragment -> three planes
+    auto split_half = [&](int hf, const f32x4& v) {
+        Split4 sp;
+        sp.r = v;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            unsigned d0, d1;
+            sp.plane(d0, d1, p < 2);
+            an[hf >> 1][p][2 * (hf & 1)] = d0;
+            an[hf >> 1][p][2 * (hf & 1) + 1] = d1;
+        }
+    };
+#define GS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define GS_PIPE(mask) __builtin_amdgcn_sched_group_barrier(mask, 1, 0)
+
+    const int nk = K / GS_BK;
+    GS_STAGE_A(0, 0)
+    GS_STAGE_A(1, 1)
+    GS_STAGE_W(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GB2_BARRIER();
+#pragma unroll
+    for (int hf = 0; hf < 8; ++hf)                     // k-tile 0 is split up front (exposed once per block)
+        split_half(hf, *(const f32x4*)(smem + (hf >> 1) * 16 * 32 + ((hf & 1) ? a_hi : a_lo)));
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];
+#ifdef GB2_CLOCK_DIAG
+    const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_last = dg_c0, dg_acc[3] = {0, 0, 0};   // cycles in: MFMA body | vmcnt + lgkmcnt wait | barrier
+#define GS_DIAG_STAMP(i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); dg_acc[i] += now - dg_last; dg_last = now; }
+#else
+#define GS_DIAG_STAMP(i)
+#endif
+
+    // One k-tile per iteration: W of slot (kt & 1) against the planes in `ap`; the fp32 A fragments of k-tile kt+1 (slot
+    // (kt+1) & 1) are read and split into `an` on the way: step b of 8 is 24 MFMAs (six terms x four row-tiles of
+    // column-tile b) with the other work of the step issued BETWEEN them -- an MFMA leaves 8 of its 16 issue cycles free:
+    //   steps 0..5  split one half-fragment each (22 VALU), step 6 two (44), step 7 moves `an` into `ap` (48 v_mov);
+    //   steps 0..3  issue this wave's 16 LDS-DMA instructions (W of k-tile kt+1, A of k-tile kt+2), 4 per step: issued
+    //               back to back they fill the vector-memory queue and stall the wave's MFMA stream;
+    //   every step reads the W fragments (and the fp32 A half) of the next step.
+    // sched_group_barrier pins that interleaving (hipcc otherwise lumps the VALU work in front of the MFMAs).  On the
+    // last k-tile the split works on stale LDS data that is never used, and the DMA descriptors have zero records.
+    for (int kt = 0; kt < nk; ++kt) {
+        const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0,
+                                                          (kt + 1 < nk) ? nrecW : 0, 0x00020000);
+        const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0,
+                                                          (kt + 2 < nk) ? nrecA : 0, 0x00020000);
+        float* Wd = smem + GS_W_BASE + ((kt + 1) & 1) * GS_W_SLOT + uwave * 64 * 16;
+        float* Ad = smem + (kt & 1) * GS_A_SLOT + uwave * 32 * 32;
+        const int kW = (kt + 1) * GS_BK * 2, kA = (kt + 2) * GS_BK * 4;
+        auto dma = [&](int d) {
+            if (GS_EXP_NODMA) return;
+            if (d < 4) {
+                GLDS16(rA, voA[d & 1], (uwave * 32 + d * 8) * lda * 4 + kA, Ad + d * 8 * 32);
+            } else {
+                const int p = (d - 4) >> 2, j = d & 3;
+                GLDS16(rW, voW, p * wplane + (uwave * 64 + j * 16) * K * 2 + kW, Wd + p * GS_W_PLANE + j * 16 * 16);
+            }
+        };
+        const float* Wv = smem + GS_W_BASE + (kt & 1) * GS_W_SLOT + b_of;
+        const float* Av = smem + ((kt + 1) & 1) * GS_A_SLOT;
+        auto a_half = [&](int hf) { return *(const f32x4*)(Av + (hf >> 1) * 16 * 32 + ((hf & 1) ? a_hi : a_lo)); };
+        u32x4 w[3];
+        f32x4 v0, v1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p] = *(const u32x4*)(Wv + p * GS_W_PLANE);
+        v0 = a_half(0);
+        GS_FENCE();
+        // (B and g are literals below: sched_group_barrier takes integer constant expressions only)
+#define GS_NREAD(B) ((B) < 5 ? 4 : (B) == 5 ? 5 : (B) == 6 ? 3 : 0)
+#define GS_NVALU(B) (GS_EXP_NOSPLIT ? ((B) == 7 ? 48 : 0) : (B) < 6 ? 22 : (B) == 6 ? 44 : 48)
+#define GS_SLOT(B, g)                                                                                           \
+        GS_PIPE(0x008);                                                                                         \
+        if (((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 > 0)                                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, ((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 > 0 ? ((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 : 1, 0); \
+        if ((B) < 4 && (g) % 6 == 2 && !GS_EXP_NODMA) GS_PIPE(0x020);
+#define GS_STEP(B)                                                                                              \
+        {                                                                                                       \
+            u32x4 wn[3];                                                                                        \
+            f32x4 vn0 = {0.f, 0.f, 0.f, 0.f}, vn1 = {0.f, 0.f, 0.f, 0.f};                                       \
+            if ((B) < 7) {                                                                                      \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(Wv + p * GS_W_PLANE + ((B) + 1) * 16 * 16); \
+                if ((B) < 5) vn0 = a_half((B) + 1);                                                             \
+                if ((B) == 5) { vn0 = a_half(6); vn1 = a_half(7); }                                             \
+            }                                                                                                   \
+            mfma4(B, 2, w[0]);      /* a3 w1 */                                                                 \
+            mfma4(B, 0, w[2]);      /* a1 w3 */                                                                 \
+            mfma4(B, 1, w[1]);      /* a2 w2 */                                                                 \
+            mfma4(B, 1, w[0]);      /* a2 w1 */                                                                 \
+            mfma4(B, 0, w[1]);      /* a1 w2 */                                                                 \
+            mfma4(B, 0, w[0]);      /* a1 w1 */                                                                 \
+            if (!GS_EXP_NOSPLIT) {                                                                              \
+                if ((B) < 6) split_half(B, v0);                                                                 \
+                if ((B) == 6) { split_half(6, v0); split_half(7, v1); }                                         \
+            }                                                                                                   \
+            if ((B) == 7) {                                                                                     \
+                _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                   \
+                    _Pragma("unroll") for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];                          \
+            }                                                                                                   \
+            if ((B) < 4) { dma(4 * (B)); dma(4 * (B) + 1); dma(4 * (B) + 2); dma(4 * (B) + 3); }                \
+            if (GS_NREAD(B) > 0) __builtin_amdgcn_sched_group_barrier(0x100, GS_NREAD(B) > 0 ? GS_NREAD(B) : 1, 0); \
+            GS_SLOT(B, 0) GS_SLOT(B, 1) GS_SLOT(B, 2) GS_SLOT(B, 3) GS_SLOT(B, 4) GS_SLOT(B, 5)                 \
+            GS_SLOT(B, 6) GS_SLOT(B, 7) GS_SLOT(B, 8) GS_SLOT(B, 9) GS_SLOT(B, 10) GS_SLOT(B, 11)               \
+            GS_SLOT(B, 12) GS_SLOT(B, 13) GS_SLOT(B, 14) GS_SLOT(B, 15) GS_SLOT(B, 16) GS_SLOT(B, 17)           \
+            GS_SLOT(B, 18) GS_SLOT(B, 19) GS_SLOT(B, 20) GS_SLOT(B, 21) GS_SLOT(B, 22) GS_SLOT(B, 23)           \
+            GS_FENCE();                                                                                         \
+            if ((B) < 7) {                                                                                      \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) w[p] = wn[p];                                     \
+                if ((B) < 6) v0 = vn0;                                                                          \
+                if ((B) == 5) v1 = vn1;                                                                         \
+            }                                                                                                   \
+        }
+        GS_STEP(0) GS_STEP(1) GS_STEP(2) GS_STEP(3) GS_STEP(4) GS_STEP(5) GS_STEP(6) GS_STEP(7)
+#undef GS_STEP
+#undef GS_SLOT
+#undef GS_NVALU
+#undef GS_NREAD
+        GS_DIAG_STAMP(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GS_DIAG_STAMP(1)
+        if (!GS_EXP_NOBAR) GB2_BARRIER();
+        GS_DIAG_STAMP(2)
+    }
+#ifdef GB2_CLOCK_DIAG
+    if (threadIdx.x == 0 && P.C2) {   // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        unsigned long long* dg = (unsigned long long*)P.C2 + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dg[0] = __builtin_amdgcn_s_memtime() - dg_c0;
+        dg[1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+        unsigned long long* dx = (unsigned long long*)P.C2 + 2 * gridDim.x * gridDim.z + 3 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dx[0] = dg_acc[0]; dx[1] = dg_acc[1]; dx[2] = dg_acc[2];
+    }
+    const unsigned long long dg_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+#undef GS_PIPE
+#undef GS_FENCE
+#undef GS_STAGE_W
+#undef GS_STAGE_A
+#undef GLDS16
+    // (the last tile ended with lgkmcnt(0) + barrier: the ring is dead, the epilogue image may overwrite it)
+    f32x16 unused[2][4];
+    gemm_t256_epilogue<true>(args, P, smem, m0, n0, unused, acc16);
+#ifdef GB2_CLOCK_DIAG
+    if (threadIdx.x == 0 && P.C2) {
+        unsigned long long* dy = (unsigned long long*)P.C2 + 5 * gridDim.x * gridDim.z + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dy[0] = dg_c0 - dg_entry;                                   // prologue: entry -> main loop
+        dy[1] = __builtin_amdgcn_s_memtime() - dg_loop_end;         // epilogue (stores issued, not necessarily landed)
+    }
+#endif
+}

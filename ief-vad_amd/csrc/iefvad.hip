@@ -17,6 +17,7 @@
 #include "common.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
+#include "gemm_split.h"
 #include "rowops.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -72,6 +73,13 @@ struct iefvad_handle {
     bf16_t* head_wb[2];
     bf16_t* ref_w1b[IEFVAD_MAX_STEPS];
     bf16_t* ref_w2b[IEFVAD_MAX_STEPS];
+    // three-plane bf16 splits [3][N][768] of the projection matrices (IEFVAD_COMPUTE_BF16X6 only)
+    bf16_t* arena_s;
+    bf16_t* in_ws[2][IEFVAD_MAX_LAYERS];
+    bf16_t* out_ws[2][IEFVAD_MAX_LAYERS];
+    bf16_t* head_ws[2];
+    bf16_t* ref_w1s[IEFVAD_MAX_STEPS];
+    bf16_t* ref_w2s[IEFVAD_MAX_STEPS];
 };
 
 // chunks per internal pass: 256 (65,536 rows, 2.8 GB of workspace) in fp32 mode; the bf16 kernels are ~100 us
@@ -102,7 +110,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         return fail("iefvad_create: num_steps %d outside 0..%d", cfg->num_steps, IEFVAD_MAX_STEPS);
     if (cfg->noise_model != IEFVAD_NOISE_GAUSSIAN && cfg->noise_model != IEFVAD_NOISE_STUDENT_T)
         return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");   // imf_vad.py:138
-    if (cfg->compute != IEFVAD_COMPUTE_F32 && cfg->compute != IEFVAD_COMPUTE_BF16)
+    if (cfg->compute != IEFVAD_COMPUTE_F32 && cfg->compute != IEFVAD_COMPUTE_BF16 && cfg->compute != IEFVAD_COMPUTE_BF16X6)
         return fail("iefvad_create: unknown compute mode %d", cfg->compute);
     if (cfg->noise_model == IEFVAD_NOISE_STUDENT_T && !(cfg->nu != 0.f))
         return fail("iefvad_create: nu must be non-zero for StudentT");
@@ -120,6 +128,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GS_LDS_BYTES);
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -132,6 +143,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
     if (h->arena_b) (void)hipFree(h->arena_b);
+    if (h->arena_s) (void)hipFree(h->arena_s);
     delete h;
 }
 
@@ -144,6 +156,20 @@ static int launch_cast(const void* in0, const void* in1, float* o0, float* o1, b
                        (const T*)in1, o0, o1, b0, b1, n);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+static int launch_split_planes(const float* src, bf16_t* planes, size_t n, hipStream_t stream) {
+    if (n % 4) return fail("split_bf16x3: n = %zu is not a multiple of 4", n);
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iefvad_split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, planes, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int iefvad_split_bf16x3(const float* src, void* planes, size_t n, void* stream) {
+    if (!src || !planes) return fail("iefvad_split_bf16x3: null argument");
+    return launch_split_planes(src, (bf16_t*)planes, n, (hipStream_t)stream);
 }
 
 extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, void* stream_) {
@@ -225,6 +251,28 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
         for (int k = 0; k < K; ++k) {
             if (int rc = conv(&h->ref_w1b[k], h->ref_w1[k], DD)) return rc;
             if (int rc = conv(&h->ref_w2b[k], h->ref_w2[k], DD)) return rc;
+        }
+    }
+    if (h->cfg.compute == IEFVAD_COMPUTE_BF16X6) {
+        // exact three-term bf16 split of every projection matrix (gemm_split.h); biases, LayerNorm, scorer stay fp32
+        const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
+        if (!h->arena_s) HIP_TRY(hipMalloc((void**)&h->arena_s, 3 * nb * sizeof(bf16_t)));
+        bf16_t* q = h->arena_s;
+        auto split = [&](bf16_t** dst, const float* src, size_t n) -> int {
+            *dst = q;
+            q += 3 * n;
+            return launch_split_planes(src, *dst, n, stream);
+        };
+        for (int m = 0; m < 2; ++m) {
+            for (int l = 0; l < L; ++l) {
+                if (int rc = split(&h->in_ws[m][l], h->in_w[m][l], 3 * DD)) return rc;
+                if (int rc = split(&h->out_ws[m][l], h->out_w[m][l], DD)) return rc;
+            }
+            if (int rc = split(&h->head_ws[m], h->head_w[m], 2 * DD)) return rc;
+        }
+        for (int k = 0; k < K; ++k) {
+            if (int rc = split(&h->ref_w1s[k], h->ref_w1[k], DD)) return rc;
+            if (int rc = split(&h->ref_w2s[k], h->ref_w2[k], DD)) return rc;
         }
     }
     h->weights_set = true;
@@ -323,6 +371,24 @@ static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& 
     return 0;
 }
 
+// BF16X6: the split kernel takes the projection when its 128 x 256 grid fills the chip (one workgroup per CU);
+// smaller problems run on the fp32 kernels (launch_gemm)
+static bool split_eligible(int M, int N, int K, int nz) {
+    return M % GS_BM == 0 && N % GS_BN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / GS_BN) * nz >= 256;
+}
+
+static int launch_gemm_split(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
+    if (a.M % GS_BM || a.N % GS_BN || a.K % 64 || a.K < 64)
+        return fail("gemm(bf16x6): shape M=%d N=%d K=%d not a multiple of the %dx%dx64 tile", a.M, a.N, a.K, GS_BM, GS_BN);
+    dim3 grid((a.M / GS_BM) * (a.N / GS_BN), 1, nz);
+    hipEvent_t e = tm.begin(stage);
+    hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, stream, a);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static size_t in_elem_bytes(int in_dtype) { return in_dtype == IEFVAD_IN_F32 ? 4 : 2; }
 
 // One projection in either arithmetic: fills the fp32 or the bf16 argument block from the same description.
@@ -331,6 +397,7 @@ struct Proj {
     const bf16_t* A16[2];     // bf16 A operand (IEFVAD_COMPUTE_BF16)
     const float* W32[2];
     const bf16_t* W16[2];
+    const bf16_t* Ws[2];      // three-plane split of W (IEFVAD_COMPUTE_BF16X6)
     const float* bias[2];
     float* C[2];              // fp32 result (nullable in bf16 mode)
     bf16_t* Cb[2];            // bf16 copy of the result (bf16 mode only, nullable)
@@ -341,7 +408,19 @@ struct Proj {
     int qcols;
 };
 
-static int launch_proj(const Proj& p, bool bf16, int rows, hipStream_t stream, Timer& tm, int stage) {
+static int launch_proj(const Proj& p, int compute, int rows, hipStream_t stream, Timer& tm, int stage) {
+    const bool bf16 = (compute == IEFVAD_COMPUTE_BF16);
+    if (compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, p.N, IEF_D, p.nz)) {
+        GemmBArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = rows; g.N = p.N; g.K = IEF_D; g.lda = IEF_D; g.ldc = p.ldc; g.epi = p.epi; g.alpha = p.alpha; g.qcols = p.qcols;
+        g.wplane = p.N * IEF_D * 2;
+        for (int m = 0; m < p.nz; ++m) {
+            g.p[m].A = (const bf16_t*)p.A32[m];          // fp32 data behind the typed pointer
+            g.p[m].W = p.Ws[m]; g.p[m].bias = p.bias[m]; g.p[m].C = p.C[m]; g.p[m].R = p.R[m]; g.p[m].C2 = p.C2[m];
+        }
+        return launch_gemm_split(g, p.nz, stream, tm, stage);
+    }
     if (!bf16) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -444,11 +523,11 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             // q is pre-scaled for the softmax by log2(e)/sqrt(96): both attention kernels use exp2
             p.alpha = qscale * 1.4426950408889634f;
             for (int m = 0; m < 2; ++m) {
-                p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l];
+                p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l]; p.Ws[m] = h->in_ws[m][l];
                 p.bias[m] = h->in_b[m][l];
                 if (bf) p.Cb[m] = qkvb[m]; else p.C[m] = qkv[m];
             }
-            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_QKV)) return rc;
+            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_QKV)) return rc;
 
             hipEvent_t e = tm.begin(ST_ATT);
             if (bf) {
@@ -469,10 +548,10 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
-                p.A32[m] = att[m]; p.A16[m] = attb[m]; p.W32[m] = h->out_w[m][l]; p.W16[m] = h->out_wb[m][l];
+                p.A32[m] = att[m]; p.A16[m] = attb[m]; p.W32[m] = h->out_w[m][l]; p.W16[m] = h->out_wb[m][l]; p.Ws[m] = h->out_ws[m][l];
                 p.bias[m] = h->out_b[m][l]; p.C[m] = ybuf[m]; p.R[m] = cur[m];
             }
-            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_OUT)) return rc;
+            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_OUT)) return rc;
 
             LnArgs la;
             memset(&la, 0, sizeof(la));
@@ -499,10 +578,10 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             memset(&p, 0, sizeof(p));
             p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
-                p.A32[m] = xbuf[m]; p.A16[m] = xb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.bias[m] = h->head_b[m];
+                p.A32[m] = xbuf[m]; p.A16[m] = xb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
             }
             p.C[0] = mu_i; p.C2[0] = lv_i; p.C[1] = mu_e; p.C2[1] = lv_e;
-            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_HEAD)) return rc;
+            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_HEAD)) return rc;
         }
 
         // 3. precision weights + fusion (imf_vad.py:130-144), fp32 in both modes
@@ -528,14 +607,14 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             Proj p;
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
-            p.A32[0] = z; p.A16[0] = zb; p.W32[0] = h->ref_w1[k]; p.W16[0] = h->ref_w1b[k]; p.bias[0] = h->ref_b1[k];
+            p.A32[0] = z; p.A16[0] = zb; p.W32[0] = h->ref_w1[k]; p.W16[0] = h->ref_w1b[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k];
             p.C[0] = bf ? nullptr : hbuf; p.Cb[0] = bf ? hb : nullptr;
-            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_REFINE)) return rc;
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
-            p.A32[0] = hbuf; p.A16[0] = hb; p.W32[0] = h->ref_w2[k]; p.W16[0] = h->ref_w2b[k]; p.bias[0] = h->ref_b2[k];
+            p.A32[0] = hbuf; p.A16[0] = hb; p.W32[0] = h->ref_w2[k]; p.W16[0] = h->ref_w2b[k]; p.Ws[0] = h->ref_w2s[k]; p.bias[0] = h->ref_b2[k];
             p.C[0] = z; p.R[0] = z; p.Cb[0] = (bf && k + 1 < K) ? zb : nullptr;
-            if (int rc = launch_proj(p, bf, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_REFINE)) return rc;
         }
 
         // 5. scorer (imf_vad.py:150)
@@ -617,6 +696,16 @@ extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias,
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS;
         g.p[0].A = (const bf16_t*)A; g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C;
         return launch_gemm_b(g, 1, (hipStream_t)stream, tm, ST_QKV);
+    }
+    if (compute == IEFVAD_COMPUTE_BF16X6) {
+        GemmBArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS; g.wplane = N * K * 2;
+        g.p[0].A = (const bf16_t*)A; g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C;
+        hipError_t e = hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           GS_LDS_BYTES);
+        if (e != hipSuccess) return fail("iefvad_gemm_bias: %s", hipGetErrorString(e));
+        return launch_gemm_split(g, 1, (hipStream_t)stream, tm, ST_QKV);
     }
     return fail("iefvad_gemm_bias: unknown compute mode %d", compute);
 }

@@ -18,11 +18,13 @@ MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
 IN_F32, IN_F16, IN_BF16 = 0, 1, 2
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X6 = 0, 1, 2
+COMPUTE_CODES = {"f32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x6": COMPUTE_BF16X6}
 
 # every symbol include/iefvad.h declares
 SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_workspace_bytes",
-           "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_last_error", "iefvad_destroy"]
+           "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_last_error",
+           "iefvad_destroy"]
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -100,6 +102,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.iefvad_gemm_bias.restype = C.c_int
+    lib.iefvad_split_bf16x3.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.iefvad_split_bf16x3.restype = C.c_int
     lib.iefvad_last_error.restype = C.c_char_p
     lib.iefvad_destroy.argtypes = [C.c_void_p]
     lib.iefvad_destroy.restype = None

@@ -115,7 +115,11 @@ class MMFMIL(nn.Module):
       compute      "f32" (default): exact-fp32 MFMA projections, the parity mode;
                    "bf16": bf16 MFMA operands with fp32 accumulation in the dense projections and in the two
                    attention products; softmax, LayerNorm, the residual stream, the fusion and the refinement
-                   state stay fp32 (BASELINE config 3).
+                   state stay fp32 (BASELINE config 3);
+                   "bf16x6": the fp32 path with every dense projection computed as six bf16 MFMA products of the exact
+                 three-term bf16 split of both fp32 operands (csrc/gemm_split.h): fp32-accurate -- held to the same
+                 tolerances as "f32" -- at the bf16 matrix-core rate.  Batches too small to fill the chip run on the
+                 "f32" kernels, so scores are fp32-accurate but not bit-identical across batch sizes in this mode.
     """
 
     def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
@@ -135,8 +139,8 @@ class MMFMIL(nn.Module):
                                      noise_model=args.noise_model, nu=args.nu)
         if outputs not in ("full", "scores"):
             raise ValueError("outputs must be 'full' or 'scores'")
-        if compute not in ("f32", "bf16"):
-            raise ValueError("compute must be 'f32' or 'bf16'")
+        if compute not in _lib.COMPUTE_CODES:
+            raise ValueError("compute must be 'f32', 'bf16' or 'bf16x6'")
         self.outputs = outputs
         self.micro_batch = micro_batch
         self.compute = compute
@@ -179,7 +183,7 @@ class MMFMIL(nn.Module):
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, embed_dim=t.embed_dim, seq_len=self.visual_length,
                           num_heads=t.num_heads, num_layers=t.num_layers, num_steps=t.num_refinement_steps,
                           noise_model=self._noise_code(),
-                          compute=_lib.COMPUTE_BF16 if self.compute == "bf16" else _lib.COMPUTE_F32, lambda_ref=float(t.lambda_ref),
+                          compute=_lib.COMPUTE_CODES[self.compute], lambda_ref=float(t.lambda_ref),
                           nu=float(t.nu), epsilon=float(t.epsilon), micro_batch=int(self.micro_batch))
         h = C.c_void_p()
         with torch.cuda.device(device):

@@ -38,9 +38,15 @@ enum { IEFVAD_NOISE_GAUSSIAN = 0, IEFVAD_NOISE_STUDENT_T = 1 };
 /* element type of the img / ev feature blocks handed to iefvad_forward (the reference casts
  * whatever arrives with `.to(torch.float)`, imf_vad.py:41-42) */
 enum { IEFVAD_IN_F32 = 0, IEFVAD_IN_F16 = 1, IEFVAD_IN_BF16 = 2 };
-/* arithmetic of the dense projections: F32 = exact-fp32 MFMA (parity mode);
- * BF16 = bf16 MFMA operands, fp32 accumulation and fp32 fusion state (throughput mode) */
-enum { IEFVAD_COMPUTE_F32 = 0, IEFVAD_COMPUTE_BF16 = 1 };
+/* arithmetic of the dense projections:
+ *   F32    = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-reproducible across batch sizes (parity mode);
+ *   BF16   = operands rounded to bf16, fp32 accumulation and fp32 fusion state (throughput mode);
+ *   BF16X6 = fp32 operands, each split exactly into three bf16 terms and multiplied as six bf16 MFMA
+ *            products with fp32 accumulation: fp32-accurate (held to the F32 mode's tolerances, product
+ *            error <= 2^-26 relative) at the bf16 matrix-core rate; everything else is the F32 path.
+ *            Small batches (grids that would not fill the chip) use the F32 kernels, so results are
+ *            fp32-accurate but not bit-identical across batch sizes in this mode. */
+enum { IEFVAD_COMPUTE_F32 = 0, IEFVAD_COMPUTE_BF16 = 1, IEFVAD_COMPUTE_BF16X6 = 2 };
 
 typedef struct iefvad_handle iefvad_handle;
 
@@ -144,9 +150,15 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
  * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);
- * bias and C are fp32 in both. */
+ * IEFVAD_COMPUTE_BF16X6: A is fp32, W is the three-plane split [3][N][K] bf16 made by iefvad_split_bf16x3
+ * (N % 256 == 0); bias and C are fp32 in all three. */
 int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C,
                      int32_t M, int32_t N, int32_t K, int32_t compute, void* stream);
+
+/* The exact three-term bf16 split of n fp32 values (n % 4 == 0): planes[0..n) = bf16(x),
+ * planes[n..2n) = bf16(x - p0), planes[2n..3n) = bf16(x - p0 - p1), round-to-nearest-even; x == p0 + p1 + p2
+ * for finite x.  What iefvad_set_weights applies to every projection matrix in IEFVAD_COMPUTE_BF16X6. */
+int iefvad_split_bf16x3(const float* src, void* planes, size_t n, void* stream);
 
 const char* iefvad_last_error(void);
 void iefvad_destroy(iefvad_handle* h);

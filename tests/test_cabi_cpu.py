@@ -24,7 +24,7 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(iefvad_[a-z_]+)\s*\(", text)))
+    declared = sorted(set(re.findall(r"\b(iefvad_[a-z0-9_]+)\s*\(", text)))
     assert declared == sorted(L.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
