@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl (= RCCL over xGMI) for real multi-GPU runs; gloo only to rehearse N>1 on a one-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra-modes", action="store_true",
+                   help="skip the short bf16x6 pass that a default (f32) run appends as `fp32_accurate_fast_mode`")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return p.parse_args()
 
@@ -83,6 +85,37 @@ def cpu_baseline(sd, seconds):
     med = float(np.median(times))
     return {"value": 8 * T / med, "unit": "snippets/s", "cores": cores, "kind": "port",
             "sample": f"oracle forward, B=8 chunks (2048 snippets) per call, median of {len(times)} calls, fp32"}
+
+
+def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
+    """The same workload on this rank's GPU in another compute mode (no gather): reported beside the headline, which
+    stays the fp32 MFMA mode.  bf16x6 = fp32-accurate projections as six bf16 MFMA products (csrc/gemm_split.h)."""
+    import iefvad_amd
+    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
+                              micro_batch=a.micro_batch, compute=compute)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    stage = {}
+    with torch.no_grad():
+        model(img, ev, None, None, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(img, ev, None, None, None, timed=True)
+            for k, v in model.last_stage_times.items():
+                stage[k] = stage.get(k, 0.0) + v
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    B = img.shape[0]
+    gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / steps
+    alg = GEMM_FLOPS_PER_SNIPPET * B * T / (gemm_ms * 1e-3) / 1e12
+    return {"compute": compute, "value": B * T * steps / dt, "unit": "snippets/s per GPU", "steps": steps,
+            "ms_per_step": dt / steps * 1e3,
+            "roofline": {"bound": "mfma", "kernel": "iefvad_gemm_split_n128_kernel", "achieved": 6.0 * alg,
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 6.0 * alg / PEAK_BF16_MFMA_TFLOPS,
+                         "algorithmic_fp32_tflops": alg, "algorithmic_vs_fp32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS},
+            "stage_ms_per_step": {k: v / steps for k, v in stage.items() if k.endswith("_ms")},
+            "parity": "held to the f32 mode's gates (tests/test_gpu_bf16x6.py): |d sigmoid| <= 2e-6, error vs fp64 <= the fp32 MFMA path's"}
 
 
 def main():
@@ -165,7 +198,7 @@ def main():
         # bf16x6: each algorithmic (fp32) multiply-add is executed as six bf16 MFMA multiply-adds
         executed = achieved * (6.0 if a.compute == "bf16x6" else 1.0)
         kernel = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_kernel",
-                  "bf16x6": "iefvad_gemm_split_kernel"}[a.compute]
+                  "bf16x6": "iefvad_gemm_split_n128_kernel"}[a.compute]
         dtype = {"f32": "f32", "bf16": "bf16", "bf16x6": "f32 (bf16x6 split products, fp32 accumulate)"}[a.compute]
         if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256 and a.compute == "f32":
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
@@ -189,6 +222,8 @@ def main():
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")},
             "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12,
         }
+        if a.compute == "f32" and not a.no_extra_modes:
+            line["fp32_accurate_fast_mode"] = extra_mode(sd, margs, dev, img, ev, a, "bf16x6")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), flush=True)

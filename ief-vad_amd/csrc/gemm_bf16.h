@@ -238,11 +238,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // time in a private padded image (the ring is dead by then; the caller has put a barrier after its last read) and
 // re-reads them row-wise, so bias / residual loads and stores are 16 bytes per lane and 512-byte row segments per
 // instruction.  MF16 selects the accumulator map (16x16 tiles in acc16, else 32x32 tiles in acc).
-template <bool MF16>
-__device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
-                                                   f32x16 (&acc)[2][4], f32x4 (&acc16)[4][8]) {
+// The wave tile is (32 PASSES) rows x 128 columns with origin (wrow0, wcol0) inside the block tile at (m0, n0).
+template <bool MF16, int PASSES>
+__device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
+                                                   int wrow0, int wcol0, f32x16 (&acc)[PASSES][4],
+                                                   f32x4 (&acc16)[2 * PASSES][8]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
     const int i = lane & 31, h = lane >> 5;
     const int r16 = lane & 15, q16 = lane >> 4;
     // ---- epilogue through LDS: the wave parks 32 rows x 128 columns at a time and re-reads them row-wise;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const 
     const int epi = args.epi, ldc = args.ldc;
     const float alpha = args.alpha;
     const int rq = lane >> 5, cq = lane & 31;
-    const int ncol = n0 + wc * 128 + 4 * cq;
+    const int ncol = n0 + wcol0 + 4 * cq;
     const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
     float* E = smem + wave * (32 * GB2_EPI_LD);       // 16.9 KB per wave
     const f32x4 bv = *(const f32x4*)(P.bias + ncol);
@@ -261,8 +262,8 @@ __device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const 
     if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
     if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int mrow = m0 + wr * 64 + a * 32 + rq;
+    for (int a = 0; a < PASSES; ++a) {
+        const int mrow = m0 + wrow0 + a * 32 + rq;
         f32x4 res[16];
         if (has_resid) {
 #pragma unroll
@@ -304,6 +305,14 @@ __device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const 
             }
         }
     }
+}
+
+// the 2 x 2 wave layout of the 128 x 256 kernels: wave (wr, wc) owns the 64 x 128 tile at (64 wr, 128 wc)
+template <bool MF16>
+__device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
+                                                   f32x16 (&acc)[2][4], f32x4 (&acc16)[4][8]) {
+    const int wave = threadIdx.x >> 6;
+    gemm_wave_epilogue<MF16, 2>(args, P, smem, m0, n0, (wave >> 1) * 64, (wave & 1) * 128, acc, acc16);
 }
 
 // One body, two element types: F32 = false -> bf16 operands (32 elements per 64-byte row, v_mfma_f32_32x32x16_bf16);

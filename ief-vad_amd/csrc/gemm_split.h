@@ -14,10 +14,14 @@
 // tests hold this mode to the SAME gates as the fp32 mode (tests/helpers.py TOL_*).  Non-finite inputs differ:
 // inf - inf in the remainder turns an inf operand into NaN (the fp32 path would propagate inf).
 //
-// Structure: 128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (32 accumulators of v_mfma_f32_16x16x32_bf16), k-tile
-// 32, ONE workgroup per CU (one wave per SIMD, ~330 of its 512 VGPR + AGPR): a k-tile is 192 MFMAs = 3072 cycles
-// per wave, long enough that a one-tile-ahead double buffer hides the LDS-DMA latency.
-//   LDS (128 KB): 2 x A slot [128 rows][128 B fp32]  +  2 x W slot 3 planes x [256 rows][64 B bf16]
+// Two configurations of one template body (NA = 16-row tiles per wave):
+//   NA = 4  128 x 256 block tile, 4 waves as 2 x 2 of 64 x 128 (32 accumulators of v_mfma_f32_16x16x32_bf16), ONE
+//           workgroup per CU (one wave per SIMD, ~330 of its 512 VGPR + AGPR); a k-tile (k = 32) is 192 MFMAs = 3072
+//           cycles per wave.  LDS 128 KB: 2 x A slot [128 rows][128 B fp32] + 2 x W slot 3 planes x [256 rows][64 B bf16]
+//   NA = 2  128 x 128 block tile, 4 waves as 4 x 1 of 32 x 128 (16 accumulators), TWO workgroups per CU (80 KB LDS, <= 256
+//           registers): one workgroup's prologue, barrier waits and epilogue (every CU storing at once is an HBM
+//           burst) run under the other's MFMAs; each wave splits only its own 32 rows (no duplicated split work).
+// Common: a one-tile-ahead double buffer filled by LDS-DMA.
 //   A is staged as fp32 (no extra HBM pass, producers keep writing fp32) and split in registers: the fragments of
 //   k-tile t+1 are read and split (11 VALU per element pair: v_cvt_pk_bf16_f32, shift / mask, exact subtractions) while
 //   the MFMAs of k-tile t run.  The A ring therefore runs one tile ahead of the W ring.
@@ -44,13 +48,12 @@
 #define GS_EXP_NOBAR 0
 #endif
 #define GS_BM 128
-#define GS_BN 256
 #define GS_BK 32
 #define GS_A_SLOT (GS_BM * 32)                  // 4-byte units: 128 rows x 128 B
-#define GS_W_PLANE (GS_BN * 16)                 // 256 rows x 64 B
-#define GS_W_SLOT (3 * GS_W_PLANE)
-#define GS_W_BASE (2 * GS_A_SLOT)
-#define GS_LDS_BYTES ((2 * GS_A_SLOT + 2 * GS_W_SLOT) * 4)   // 131,072 B
+#define GS_BN_OF(NA) ((NA) == 4 ? 256 : 128)
+#define GS_LDS_BYTES_OF(NA) ((2 * GS_A_SLOT + 2 * 3 * GS_BN_OF(NA) * 16) * 4)   // 131,072 B (NA = 4) / 81,920 B (NA = 2)
+#define GS_BN GS_BN_OF(4)                       // the one-workgroup-per-CU configuration
+#define GS_LDS_BYTES GS_LDS_BYTES_OF(4)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -93,29 +96,36 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int NA>
+__device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* smem) {
+    constexpr int BN = GS_BN_OF(NA);
+    constexpr int W_PLANE = BN * 16;                   // 4-byte units: BN rows x 64 B
+    constexpr int W_SLOT = 3 * W_PLANE;
+    constexpr int W_BASE = 2 * GS_A_SLOT;
+    constexpr int WROWS = BN / 4;                      // W rows staged per wave and plane
+    constexpr int NM = 6 * NA;                         // MFMAs per step (24 / 12)
 #ifdef GB2_CLOCK_DIAG
     const unsigned long long dg_entry = __builtin_amdgcn_s_memtime();
 #endif
     const GemmBProblem& P = args.p[blockIdx.z];
-    const int ntn = args.N / GS_BN;
+    const int ntn = args.N / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int m0 = tm * GS_BM, n0 = tn * GS_BN;
+    const int m0 = tm * GS_BM, n0 = tn * BN;
     const int K = args.K, lda = args.lda;
     const int wplane = args.wplane;                    // bytes between the bf16 planes of W
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wrow0 = NA == 4 ? (wave >> 1) * 64 : wave * 32;      // origin of the wave tile inside the block tile
+    const int wcol0 = NA == 4 ? (wave & 1) * 128 : 0;
     const int r16 = lane & 15, q16 = lane >> 4;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
 
     // ---- staging (LDS-DMA, lane-linear 1 KB images; the swizzle is applied to the SOURCE chunk) ----
     // A: one instruction = 8 rows x 128 B; wave w, instruction j -> rows 32 w + 8 j + (lane >> 3), chunk lane & 7
-    // W: one instruction = 16 rows x 64 B; wave w, plane p, instruction j -> rows 64 w + 16 j + (lane >> 2), chunk lane & 3
-    const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = 2 * wplane + (int)((GS_BN - 1) * K + K) * 2;
+    // W: one instruction = 16 rows x 64 B; wave w, plane p, instruction j -> rows WROWS w + 16 j + (lane >> 2), chunk lane & 3
+    const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = 2 * wplane + (int)((BN - 1) * K + K) * 2;
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0, nrecA, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0, nrecW, 0x00020000);
     const int arow = lane >> 3, achk = lane & 7;
@@ -126,37 +136,36 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
     const int voW = wrow * K * 2 + ((wchk ^ ((0xD2 >> (2 * ((wrow >> 2) & 3))) & 3)) << 4);
 #define GLDS16(rs, vo, so, lp) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
-#define GS_STAGE_A(tile, slot)                                                                                  \
-    {                                                                                                           \
-        float* Ad = smem + (slot) * GS_A_SLOT + uwave * 32 * 32;                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
-            GLDS16(rsA, voA[j & 1], ((uwave * 32 + j * 8) * lda + (tile) * GS_BK) * 4, Ad + j * 8 * 32);        \
-    }
-#define GS_STAGE_W(tile, slot)                                                                                  \
-    {                                                                                                           \
-        float* Wd = smem + GS_W_BASE + (slot) * GS_W_SLOT + uwave * 64 * 16;                                    \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-                GLDS16(rsW, voW, p * wplane + ((uwave * 64 + j * 16) * K + (tile) * GS_BK) * 2,                 \
-                       Wd + p * GS_W_PLANE + j * 16 * 16);                                                      \
-    }
+    auto stage_a = [&](int tile, int slot) {
+        float* Ad = smem + slot * GS_A_SLOT + uwave * 32 * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) GLDS16(rsA, voA[j & 1], ((uwave * 32 + j * 8) * lda + tile * GS_BK) * 4, Ad + j * 8 * 32);
+    };
+    auto stage_w = [&](int tile, int slot) {
+        float* Wd = smem + W_BASE + slot * W_SLOT + uwave * WROWS * 16;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < WROWS / 16; ++j)
+                GLDS16(rsW, voW, p * wplane + ((uwave * WROWS + j * 16) * K + tile * GS_BK) * 2, Wd + p * W_PLANE + j * 16 * 16);
+    };
 
     // ---- fragment addresses (4-byte units) ----
     const int swa = (r16 >> 1) & 5;
-    const int a_lo = (wr * 64 + r16) * 32 + (((2 * q16) ^ swa) << 2);
-    const int a_hi = (wr * 64 + r16) * 32 + (((2 * q16 + 1) ^ swa) << 2);
-    const int b_of = (wc * 128 + r16) * 16 + ((q16 ^ ((0xD2 >> (2 * ((r16 >> 2) & 3))) & 3)) << 2);
+    const int a_lo = (wrow0 + r16) * 32 + (((2 * q16) ^ swa) << 2);
+    const int a_hi = (wrow0 + r16) * 32 + (((2 * q16 + 1) ^ swa) << 2);
+    const int b_of = (wcol0 + r16) * 16 + ((q16 ^ ((0xD2 >> (2 * ((r16 >> 2) & 3))) & 3)) << 2);
 
-    f32x4 acc16[4][8];
+    f32x4 acc16[NA][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ap[4][3], an[4][3];                          // bf16 planes of the A fragments: current k-tile / next k-tile
-    auto mfma4 = [&](int b, int pa, const u32x4& wv) {
+    u32x4 ap[NA][3], an[NA][3];                        // bf16 planes of the A fragments: current k-tile / next k-tile
+    auto mfma_row = [&](int b, int pa, const u32x4& wv) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
             acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[a][pa]),
                                                                   __builtin_bit_cast(bf16x8, wv), acc16[a][b], 0, 0, 0);
     };
@@ -176,16 +185,16 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
 #define GS_PIPE(mask) __builtin_amdgcn_sched_group_barrier(mask, 1, 0)
 
     const int nk = K / GS_BK;
-    GS_STAGE_A(0, 0)
-    GS_STAGE_A(1, 1)
-    GS_STAGE_W(0, 0)
+    stage_a(0, 0);
+    stage_a(1, 1);
+    stage_w(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GB2_BARRIER();
 #pragma unroll
-    for (int hf = 0; hf < 8; ++hf)                     // k-tile 0 is split up front (exposed once per block)
+    for (int hf = 0; hf < 2 * NA; ++hf)                // k-tile 0 is split up front (exposed once per block)
         split_half(hf, *(const f32x4*)(smem + (hf >> 1) * 16 * 32 + ((hf & 1) ? a_hi : a_lo)));
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];
 #ifdef GB2_CLOCK_DIAG
@@ -197,11 +206,13 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
 #endif
 
     // One k-tile per iteration: W of slot (kt & 1) against the planes in `ap`; the fp32 A fragments of k-tile kt+1 (slot
-    // (kt+1) & 1) are read and split into `an` on the way: step b of 8 is 24 MFMAs (six terms x four row-tiles of
-    // column-tile b) with the other work of the step issued BETWEEN them -- an MFMA leaves 8 of its 16 issue cycles free:
-    //   steps 0..5  split one half-fragment each (22 VALU), step 6 two (44), step 7 moves `an` into `ap` (48 v_mov);
-    //   steps 0..3  issue this wave's 16 LDS-DMA instructions (W of k-tile kt+1, A of k-tile kt+2), 4 per step: issued
-    //               back to back they fill the vector-memory queue and stall the wave's MFMA stream;
+    // (kt+1) & 1) are read and split into `an` on the way.  Step B of 8 is the 6 NA MFMAs of column-tile B (six terms x
+    // NA row-tiles) with the other work of the step issued BETWEEN them:
+    //   NA = 4: steps 0..5 split one half-fragment each (22 VALU), step 6 two (44); NA = 2: steps 0..3 one each;
+    //   step 7 moves `an` into `ap` (12 NA v_mov);
+    //   the wave's LDS-DMA instructions (A of k-tile kt+2, then W of k-tile kt+1) go out 4 per step in steps 0..3
+    //   (NA = 4) / 2 per step in steps 0..4 (NA = 2): issued back to back they fill the vector-memory queue and stall
+    //   the wave's MFMA stream;
     //   every step reads the W fragments (and the fp32 A half) of the next step.
     // sched_group_barrier pins that interleaving (hipcc otherwise lumps the VALU work in front of the MFMAs).  On the
     // last k-tile the split works on stale LDS data that is never used, and the DMA descriptors have zero records.
@@ -210,59 +221,64 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
                                                           (kt + 1 < nk) ? nrecW : 0, 0x00020000);
         const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0,
                                                           (kt + 2 < nk) ? nrecA : 0, 0x00020000);
-        float* Wd = smem + GS_W_BASE + ((kt + 1) & 1) * GS_W_SLOT + uwave * 64 * 16;
+        float* Wd = smem + W_BASE + ((kt + 1) & 1) * W_SLOT + uwave * WROWS * 16;
         float* Ad = smem + (kt & 1) * GS_A_SLOT + uwave * 32 * 32;
         const int kW = (kt + 1) * GS_BK * 2, kA = (kt + 2) * GS_BK * 4;
-        auto dma = [&](int d) {
+        auto dma = [&](int d) {                        // d = 0..3: A, d = 4..: W (plane-major)
             if (GS_EXP_NODMA) return;
             if (d < 4) {
                 GLDS16(rA, voA[d & 1], (uwave * 32 + d * 8) * lda * 4 + kA, Ad + d * 8 * 32);
             } else {
-                const int p = (d - 4) >> 2, j = d & 3;
-                GLDS16(rW, voW, p * wplane + (uwave * 64 + j * 16) * K * 2 + kW, Wd + p * GS_W_PLANE + j * 16 * 16);
+                const int p = (d - 4) / (WROWS / 16), j = (d - 4) % (WROWS / 16);
+                GLDS16(rW, voW, p * wplane + (uwave * WROWS + j * 16) * K * 2 + kW, Wd + p * W_PLANE + j * 16 * 16);
             }
         };
-        const float* Wv = smem + GS_W_BASE + (kt & 1) * GS_W_SLOT + b_of;
+        const float* Wv = smem + W_BASE + (kt & 1) * W_SLOT + b_of;
         const float* Av = smem + ((kt + 1) & 1) * GS_A_SLOT;
         auto a_half = [&](int hf) { return *(const f32x4*)(Av + (hf >> 1) * 16 * 32 + ((hf & 1) ? a_hi : a_lo)); };
         u32x4 w[3];
-        f32x4 v0, v1;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = *(const u32x4*)(Wv + p * GS_W_PLANE);
+        for (int p = 0; p < 3; ++p) w[p] = *(const u32x4*)(Wv + p * W_PLANE);
         v0 = a_half(0);
         GS_FENCE();
         // (B and g are literals below: sched_group_barrier takes integer constant expressions only)
-#define GS_NREAD(B) ((B) < 5 ? 4 : (B) == 5 ? 5 : (B) == 6 ? 3 : 0)
-#define GS_NVALU(B) (GS_EXP_NOSPLIT ? ((B) == 7 ? 48 : 0) : (B) < 6 ? 22 : (B) == 6 ? 44 : 48)
+#define GS_NSPLIT(B) (NA == 4 ? ((B) < 6 ? 1 : (B) == 6 ? 2 : 0) : ((B) < 4 ? 1 : 0))       /* half-fragments split in step B */
+#define GS_NAREAD(B) ((B) < 7 ? GS_NSPLIT((B) + 1) : 0)                                      /* fp32 A reads for step B+1 */
+#define GS_NREAD(B) (((B) < 7 ? 3 : 0) + GS_NAREAD(B))
+#define GS_NDMA(B) (NA == 4 ? ((B) < 4 ? 4 : 0) : ((B) < 5 ? 2 : 0))
+#define GS_NVALU(B) ((B) == 7 ? 12 * NA : GS_EXP_NOSPLIT ? 0 : 22 * GS_NSPLIT(B))
+#define GS_VSLOT(B, g) (((g) + 1) * GS_NVALU(B) / NM - (g) * GS_NVALU(B) / NM)
 #define GS_SLOT(B, g)                                                                                           \
-        GS_PIPE(0x008);                                                                                         \
-        if (((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 > 0)                                          \
-            __builtin_amdgcn_sched_group_barrier(0x002, ((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 > 0 ? ((g) + 1) * GS_NVALU(B) / 24 - (g) * GS_NVALU(B) / 24 : 1, 0); \
-        if ((B) < 4 && (g) % 6 == 2 && !GS_EXP_NODMA) GS_PIPE(0x020);
+        if ((g) < NM) {                                                                                         \
+            GS_PIPE(0x008);                                                                                     \
+            if (GS_VSLOT(B, g) > 0) __builtin_amdgcn_sched_group_barrier(0x002, GS_VSLOT(B, g) > 0 ? GS_VSLOT(B, g) : 1, 0); \
+            if (GS_NDMA(B) > 0 && !GS_EXP_NODMA && (g) % (NM / 4) == 2 && (g) / (NM / 4) < GS_NDMA(B)) GS_PIPE(0x020); \
+        }
 #define GS_STEP(B)                                                                                              \
         {                                                                                                       \
             u32x4 wn[3];                                                                                        \
             f32x4 vn0 = {0.f, 0.f, 0.f, 0.f}, vn1 = {0.f, 0.f, 0.f, 0.f};                                       \
             if ((B) < 7) {                                                                                      \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(Wv + p * GS_W_PLANE + ((B) + 1) * 16 * 16); \
-                if ((B) < 5) vn0 = a_half((B) + 1);                                                             \
-                if ((B) == 5) { vn0 = a_half(6); vn1 = a_half(7); }                                             \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(Wv + p * W_PLANE + ((B) + 1) * 16 * 16); \
+                if (GS_NAREAD(B) == 1) vn0 = a_half((B) + 1);                                                   \
+                if (GS_NAREAD(B) == 2) { vn0 = a_half((B) + 1); vn1 = a_half((B) + 2); }                        \
             }                                                                                                   \
-            mfma4(B, 2, w[0]);      /* a3 w1 */                                                                 \
-            mfma4(B, 0, w[2]);      /* a1 w3 */                                                                 \
-            mfma4(B, 1, w[1]);      /* a2 w2 */                                                                 \
-            mfma4(B, 1, w[0]);      /* a2 w1 */                                                                 \
-            mfma4(B, 0, w[1]);      /* a1 w2 */                                                                 \
-            mfma4(B, 0, w[0]);      /* a1 w1 */                                                                 \
+            mfma_row(B, 2, w[0]);      /* a3 w1 */                                                              \
+            mfma_row(B, 0, w[2]);      /* a1 w3 */                                                              \
+            mfma_row(B, 1, w[1]);      /* a2 w2 */                                                              \
+            mfma_row(B, 1, w[0]);      /* a2 w1 */                                                              \
+            mfma_row(B, 0, w[1]);      /* a1 w2 */                                                              \
+            mfma_row(B, 0, w[0]);      /* a1 w1 */                                                              \
             if (!GS_EXP_NOSPLIT) {                                                                              \
-                if ((B) < 6) split_half(B, v0);                                                                 \
-                if ((B) == 6) { split_half(6, v0); split_half(7, v1); }                                         \
+                if (GS_NSPLIT(B) >= 1) split_half(B, v0);                                                       \
+                if (GS_NSPLIT(B) == 2) split_half((B) + 1, v1);                                                 \
             }                                                                                                   \
             if ((B) == 7) {                                                                                     \
-                _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                   \
+                _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                  \
                     _Pragma("unroll") for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];                          \
             }                                                                                                   \
-            if ((B) < 4) { dma(4 * (B)); dma(4 * (B) + 1); dma(4 * (B) + 2); dma(4 * (B) + 3); }                \
+            _Pragma("unroll") for (int d = 0; d < GS_NDMA(B); ++d) dma(GS_NDMA(B) * (B) + d);                   \
             if (GS_NREAD(B) > 0) __builtin_amdgcn_sched_group_barrier(0x100, GS_NREAD(B) > 0 ? GS_NREAD(B) : 1, 0); \
             GS_SLOT(B, 0) GS_SLOT(B, 1) GS_SLOT(B, 2) GS_SLOT(B, 3) GS_SLOT(B, 4) GS_SLOT(B, 5)                 \
             GS_SLOT(B, 6) GS_SLOT(B, 7) GS_SLOT(B, 8) GS_SLOT(B, 9) GS_SLOT(B, 10) GS_SLOT(B, 11)               \
@@ -271,15 +287,19 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
             GS_FENCE();                                                                                         \
             if ((B) < 7) {                                                                                      \
                 _Pragma("unroll") for (int p = 0; p < 3; ++p) w[p] = wn[p];                                     \
-                if ((B) < 6) v0 = vn0;                                                                          \
-                if ((B) == 5) v1 = vn1;                                                                         \
+                if (GS_NAREAD(B) >= 1) v0 = vn0;                                                                \
+                if (GS_NAREAD(B) == 2) v1 = vn1;                                                                \
             }                                                                                                   \
         }
         GS_STEP(0) GS_STEP(1) GS_STEP(2) GS_STEP(3) GS_STEP(4) GS_STEP(5) GS_STEP(6) GS_STEP(7)
 #undef GS_STEP
 #undef GS_SLOT
+#undef GS_VSLOT
 #undef GS_NVALU
+#undef GS_NDMA
 #undef GS_NREAD
+#undef GS_NAREAD
+#undef GS_NSPLIT
         GS_DIAG_STAMP(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -299,12 +319,10 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
 #endif
 #undef GS_PIPE
 #undef GS_FENCE
-#undef GS_STAGE_W
-#undef GS_STAGE_A
 #undef GLDS16
     // (the last tile ended with lgkmcnt(0) + barrier: the ring is dead, the epilogue image may overwrite it)
-    f32x16 unused[2][4];
-    gemm_t256_epilogue<true>(args, P, smem, m0, n0, unused, acc16);
+    f32x16 unused[NA / 2][4];
+    gemm_wave_epilogue<true, NA / 2>(args, P, smem, m0, n0, wrow0, wcol0, unused, acc16);
 #ifdef GB2_CLOCK_DIAG
     if (threadIdx.x == 0 && P.C2) {
         unsigned long long* dy = (unsigned long long*)P.C2 + 5 * gridDim.x * gridDim.z + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
@@ -312,4 +330,16 @@ __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs arg
         dy[1] = __builtin_amdgcn_s_memtime() - dg_loop_end;         // epilogue (stores issued, not necessarily landed)
     }
 #endif
+}
+
+// 128 x 256, one workgroup per CU
+__global__ __launch_bounds__(256, 1) void iefvad_gemm_split_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_split_body<4>(args, smem);
+}
+
+// 128 x 128, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_split_n128_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_split_body<2>(args, smem);
 }

@@ -129,8 +129,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GS_LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GS_LDS_BYTES_OF(2));
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -371,18 +371,20 @@ static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& 
     return 0;
 }
 
-// BF16X6: the split kernel takes the projection when its 128 x 256 grid fills the chip (one workgroup per CU);
-// smaller problems run on the fp32 kernels (launch_gemm)
+// BF16X6: the split kernel (128 x 128 tiles, two workgroups per CU; tools/gemm_tune_split: +5..8 % over the 128 x 256 /
+// one-workgroup configuration, same bits) takes the projection when its grid fills the chip; smaller problems run on the
+// fp32 kernels (launch_gemm)
+static const int kSplitBN = GS_BN_OF(2);
 static bool split_eligible(int M, int N, int K, int nz) {
-    return M % GS_BM == 0 && N % GS_BN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / GS_BN) * nz >= 256;
+    return M % GS_BM == 0 && N % kSplitBN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / kSplitBN) * nz >= 512;
 }
 
 static int launch_gemm_split(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
-    if (a.M % GS_BM || a.N % GS_BN || a.K % 64 || a.K < 64)
-        return fail("gemm(bf16x6): shape M=%d N=%d K=%d not a multiple of the %dx%dx64 tile", a.M, a.N, a.K, GS_BM, GS_BN);
-    dim3 grid((a.M / GS_BM) * (a.N / GS_BN), 1, nz);
+    if (a.M % GS_BM || a.N % kSplitBN || a.K % 64 || a.K < 64)
+        return fail("gemm(bf16x6): shape M=%d N=%d K=%d not a multiple of the %dx%dx64 tile", a.M, a.N, a.K, GS_BM, kSplitBN);
+    dim3 grid((a.M / GS_BM) * (a.N / kSplitBN), 1, nz);
     hipEvent_t e = tm.begin(stage);
-    hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), stream, a);
     tm.end(e);
     tm.gemm_launches += 1;
     HIP_TRY(hipGetLastError());
@@ -702,8 +704,8 @@ extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias,
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.epi = EPI_BIAS; g.wplane = N * K * 2;
         g.p[0].A = (const bf16_t*)A; g.p[0].W = (const bf16_t*)W; g.p[0].bias = bias; g.p[0].C = C;
-        hipError_t e = hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           GS_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)iefvad_gemm_split_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           GS_LDS_BYTES_OF(2));
         if (e != hipSuccess) return fail("iefvad_gemm_bias: %s", hipGetErrorString(e));
         return launch_gemm_split(g, 1, (hipStream_t)stream, tm, ST_QKV);
     }

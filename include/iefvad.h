@@ -151,7 +151,7 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
  * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);
  * IEFVAD_COMPUTE_BF16X6: A is fp32, W is the three-plane split [3][N][K] bf16 made by iefvad_split_bf16x3
- * (N % 256 == 0); bias and C are fp32 in all three. */
+ * (K % 64 == 0); bias and C are fp32 in all three. */
 int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C,
                      int32_t M, int32_t N, int32_t K, int32_t compute, void* stream);
 

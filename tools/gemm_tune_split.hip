@@ -25,7 +25,9 @@ static float run(const Variant& v, GemmBArgs gs, GemmBArgs gf, int iters) {
     CK(hipEventRecord(e0));
     for (int it = 0; it < iters; ++it) {
         dim3 grid((gs.M / GS_BM) * (gs.N / GS_BN), 1, 1);
+        dim3 grid2((gs.M / GS_BM) * (gs.N / 128), 1, 1);
         if (v.kind == 0) hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, 0, gs);
+        else if (v.kind == 2) hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid2, dim3(256), GS_LDS_BYTES_OF(2), 0, gs);
         else hipLaunchKernelGGL(iefvad_gemm_f32_t256_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, gf);
     }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -52,6 +54,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bias, hb.data(), NW * 4, hipMemcpyHostToDevice));
     CK(hipMemset(R, 0, (size_t)M * NW * 4));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES_OF(2)));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     for (int ni = 0; ni < 2; ++ni) {
         const int N = Ns[ni];
@@ -83,9 +86,17 @@ int main(int argc, char** argv) {
                 es = std::max(es, a); ef = std::max(ef, b); ss += a * a; sf += b * b; ++cnt;
             }
         double md = 0; for (size_t q = 0; q < cs.size(); ++q) md = std::max(md, (double)fabs(cs[q] - cf[q]));
+        {   // the 128 x 128 configuration must give the same bits as the 128 x 256 one (same k order per output)
+            const Variant vn0 = {"split n128", 2, EPI_BIAS, true};
+            std::vector<float> cn((size_t)M * N);
+            CK(hipMemset(C, 0, cs.size() * 4)); run(vn0, gs, gf, 1); CK(hipMemcpy(cn.data(), C, cn.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t q = 0; q < cs.size(); ++q) bad += (cn[q] != cs[q]);
+            printf("N=%d: split n128 vs split: %zu mismatching elements of %zu\n", N, bad, cs.size());
+        }
         printf("N=%d accuracy vs fp64 on %zu sampled outputs: split max %.3g rms %.3g | fp32 MFMA max %.3g rms %.3g | split vs fp32 MFMA max %.3g\n",
                N, cnt, es, sqrt(ss / cnt), ef, sqrt(sf / cnt), md);
         const Variant vs[] = {{"split bias C32", 0, EPI_BIAS, true}, {"split refine C32", 0, EPI_REFINE, true}, {"split none", 0, EPI_BIAS, false},
+                              {"n128  bias C32", 2, EPI_BIAS, true}, {"n128  refine C32", 2, EPI_REFINE, true}, {"n128  none", 2, EPI_BIAS, false},
                               {"f32   bias C32", 1, EPI_BIAS, true}, {"f32   refine C32", 1, EPI_REFINE, true}, {"f32   none", 1, EPI_BIAS, false}};
         const int nv = sizeof(vs) / sizeof(vs[0]);
         std::vector<std::vector<float>> t(nv);
@@ -100,12 +111,17 @@ int main(int argc, char** argv) {
     }
 #ifdef GB2_CLOCK_DIAG
     {   // in-kernel clock and cycles of the split main loop under sustained load
-        unsigned long long* dclk; CK(hipMalloc(&dclk, 64 * 4096));
+        unsigned long long* dclk; CK(hipMalloc(&dclk, 64 * 8192));
         GemmBArgs g; memset(&g, 0, sizeof(g));
         g.M = M; g.N = 768; g.K = K; g.lda = K; g.ldc = 768; g.epi = EPI_BIAS; g.wplane = 768 * K * 2;
         g.p[0].A = (const bf16_t*)A; g.p[0].W = Wp; g.p[0].bias = bias; g.p[0].C = C; g.p[0].C2 = (float*)dclk; g.p[1] = g.p[0];
-        dim3 grid((M / GS_BM) * (768 / GS_BN), 1, 1);
-        for (int it = 0; it < 4000; ++it) hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, 0, g);
+      for (int cfgi = 0; cfgi < 2; ++cfgi) {
+        dim3 grid((M / GS_BM) * (768 / (cfgi ? 128 : GS_BN)), 1, 1);
+        printf("%s\n", cfgi ? "128 x 128, two workgroups per CU:" : "128 x 256, one workgroup per CU:");
+        for (int it = 0; it < 4000; ++it) {
+            if (cfgi) hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), 0, g);
+            else hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, 0, g);
+        }
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> c(7 * grid.x); CK(hipMemcpy(c.data(), dclk, c.size() * 8, hipMemcpyDeviceToHost));
         {
@@ -124,8 +140,9 @@ int main(int argc, char** argv) {
         std::vector<double> ghz; std::vector<unsigned long long> cyc;
         for (size_t b = 0; b < grid.x; ++b) { ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1); cyc.push_back(c[2 * b]); }
         std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
-        printf("split main loop in-kernel clock: median %.3f GHz (min %.3f max %.3f); loop cycles median %llu (ideal 24 x 3072 = 73728)\n",
+        printf("split main loop in-kernel clock: median %.3f GHz (min %.3f max %.3f); loop cycles median %llu (ideal 24 x 3072 = 73728 / 24 x 1536 = 36864 per wave)\n",
                ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
+      }
     }
 #endif
     return 0;
