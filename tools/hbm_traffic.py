@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch of one kernel from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+separately, as MI355X_MICROARCH.md's HBM section prescribes), calibrated on iefvad_layernorm_kernel, which streams a
+known byte count in the same passes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled when the calibration
+shows 1/2).  usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring>
+                                   <rows per launch> <out.json> "<source description>" """
+import csv
+import json
+import sys
+
+fetch_csv, write_csv, kname, rows, out, source = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
+
+
+def means(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+f, w = means(fetch_csv, "FETCH_SIZE"), means(write_csv, "WRITE_SIZE")
+pick = lambda d, sub: next((v for k, v in d.items() if sub in k), None)
+ln_f, ln_w = pick(f, "iefvad_layernorm_kernel"), pick(w, "iefvad_layernorm_kernel")
+ln_bytes = 2 * rows * 768 * 4                                  # both modalities, one fp32 tensor in, one out
+fetch_scale = round(ln_bytes / (ln_f[0] * 1024))               # 2 on gfx950
+kf, kw = pick(f, kname), pick(w, kname)
+res = {"source": source, "kernel": kname, "launches_measured": kf[1],
+       "FETCH_SIZE_KB_mean": kf[0], "WRITE_SIZE_KB_mean": kw[0],
+       "calibration": f"iefvad_layernorm_kernel streams {ln_bytes} B in and out: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
+                      f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}",
+       "read_bytes_per_launch": kf[0] * 1024 * fetch_scale, "write_bytes_per_launch": kw[0] * 1024,
+       "traffic_bytes_per_launch": kf[0] * 1024 * fetch_scale + kw[0] * 1024}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
