@@ -47,6 +47,9 @@
 #ifndef GS_EXP_NOBAR
 #define GS_EXP_NOBAR 0
 #endif
+#ifndef GS_PN              // column tiles per L2-resident group (0 = all of them), see the tile map in gemm_split_body
+#define GS_PN 6
+#endif
 #define GS_BM 128
 #define GS_BK 32
 #define GS_A_SLOT (GS_BM * 32)                  // 4-byte units: 128 rows x 128 B
@@ -108,9 +111,22 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     const unsigned long long dg_entry = __builtin_amdgcn_s_memtime();
 #endif
     const GemmBProblem& P = args.p[blockIdx.z];
+    // Tile map.  xcd_remap gives each XCD a contiguous range of `bid`; the workgroups resident on an XCD at one time are
+    // consecutive bids.  Column tiles are taken in groups of PN: inside a group the order is (row panel, column tile of
+    // the group), so the resident set is (64 / PN) row panels x PN column tiles: each A panel is fetched once for its PN
+    // co-running blocks and the group's W planes (PN x 590 KB at K = 768) stay in the 4 MB L2 instead of being re-read
+    // from the Infinity Cache by every panel (N = 2304 with all 18 column tiles in flight: 10.6 MB of W planes per panel,
+    // profiles/r01_gemm_split_hbm_traffic.json).  A is re-read once per group (N / (128 PN) times per launch).
     const int ntn = args.N / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / ntn, tn = bid - tm * ntn;
+    int tm, tn;
+    {
+        const int pn = (GS_PN > 0 && ntn % GS_PN == 0) ? GS_PN : ntn;
+        const int ntm = args.M / GS_BM;
+        const int grp = bid / (ntm * pn), rem = bid - grp * (ntm * pn);
+        tm = rem / pn;
+        tn = grp * pn + (rem - tm * pn);
+    }
     const int m0 = tm * GS_BM, n0 = tn * BN;
     const int K = args.K, lda = args.lda;
     const int wplane = args.wplane;                    // bytes between the bf16 planes of W
