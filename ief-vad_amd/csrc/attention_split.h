@@ -1,0 +1,201 @@
+// Unmasked temporal self-attention over one 256-snippet window, fp32-accurate on the bf16 matrix cores (bf16x6 mode).
+//
+// Same semantics and the same S^T = K Q^T structure as attention_f32.h (/root/reference/model/imf_vad.py:69-72,115,121):
+// per (chunk, head) softmax(Q K^T / sqrt(96)) V over ALL 256 keys, q pre-scaled by log2(e)/sqrt(96) in the in_proj
+// epilogue, fp32 q | k | v in, fp32 out.  Both contractions are computed as in gemm_split.h: each fp32 operand is the
+// exact sum of three bf16 terms (round-to-nearest of the running remainder) and a product is accumulated in fp32 from
+// the six bf16 MFMA products of relative size >= 2^-18 (k3 q1 + k1 q3 + k2 q2 + k2 q1 + k1 q2 + k1 q1, and the same for
+// P V); the dropped terms are <= 2^-26 of the product.  Softmax is fp32 on the accumulators, as in the fp32 kernel.
+//
+// One workgroup = (head, chunk, modality, query half): 4 waves x 32 queries, two workgroups per CU (78 KB LDS).
+// K then V stream through a double-buffered 64-key tile.  The STAGING threads split the tile: global fp32 loads of tile
+// i+1 are issued before the MFMAs of tile i, split in registers after them (132 VALU per thread) and written to the
+// other LDS buffer as three bf16 plane images, so the MFMA phase reads ready bf16 fragments and no split is repeated
+// per wave:
+//   K planes [64 keys][104 bf16] (208-byte rows: conflict-free ds_read_b128, as attention_bf16.h)  A operand of K Q^T
+//   V planes [64 keys][ 96 bf16] (192-byte rows)  B operand of P V through ds_read_b64_tr_b16
+// v_mfma_f32_32x32x16_bf16: lane (i, h) supplies K[key i][d = 16 s + 8 h .. +7] / Q[query i][same d]; in the 32x32
+// accumulator the lane is the query and the registers are keys, so registers 8 s2 .. 8 s2 + 7 of a key tile ARE (after
+// the three-term split) the A fragments of k-step s2 of P V, in the permuted key order 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
+// that the transposed V read reproduces (attention_bf16.h).  Q is split once into registers (72 VGPRs).
+// Per 64-key tile and wave: 72 MFMAs of 32 cycles against 96 of 64 cycles in the fp32 kernel.
+#pragma once
+#include "attention_f32.h"
+#include "gemm_split.h"
+
+#define ATS_KROW 104                                   // bf16 elements per K-plane row (208 B)
+#define ATS_VROW 96                                    // bf16 elements per V-plane row (192 B)
+#define ATS_KPLANE (ATT_TK * ATS_KROW)                 // bf16 elements per plane of a K tile
+#define ATS_VPLANE (ATT_TK * ATS_VROW)
+#define ATS_BUF (3 * ATS_KPLANE)                       // bf16 elements per tile buffer (the K layout is the larger)
+#define ATS_LDS_BYTES (2 * ATS_BUF * 2)                // 79,872 B
+
+// eight fp32 -> three bf16x8 planes (exact three-term split)
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+    Split4 a, b;
+    a.r = lo;
+    b.r = hi;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        unsigned d0, d1, d2, d3;
+        a.plane(d0, d1, p < 2);
+        b.plane(d2, d3, p < 2);
+        pl[p] = u32x4{d0, d1, d2, d3};
+    }
+}
+
+#define ATS_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+// c += x * y from the planes of x (A operand) and y (B operand), smallest terms first
+#define ATS_SIX(xp, yp, c)  \
+    ATS_MFMA(xp[2], yp[0], c); ATS_MFMA(xp[0], yp[2], c); ATS_MFMA(xp[1], yp[1], c); \
+    ATS_MFMA(xp[1], yp[0], c); ATS_MFMA(xp[0], yp[1], c); ATS_MFMA(xp[0], yp[0], c)
+
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs args) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
+    const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
+    const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
+    float* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int q0 = qhalf * 128 + wave * 32;
+
+    // staging map: a 64-row x 24-chunk (4 floats) tile; thread t moves rows (t >> 3) + 32 (j & 1), chunks (t & 7) + 8 (j >> 1),
+    // j = 0..5: eight lanes cover one 128-byte line, and every offset is a constant added to two per-thread bases
+    const int srow0 = t >> 3, sch0 = t & 7;
+    const float* gsrc = qkv + (size_t)srow0 * (3 * IEF_D) + sch0 * 4;
+    f32x4 stg[6];
+    // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
+#define ATS_LOAD(ti)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
+        stg[j] = *(const f32x4*)(gsrc + (size_t)(((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +          \
+                                 ((ti) < 4 ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
+    // split the staged fp32 chunks and write the three bf16 plane images of tile ti into buffer `buf`
+#define ATS_WRITE(ti, buf)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
+        Split4 sp;                                                                                            \
+        sp.r = stg[j];                                                                                        \
+        const int rowlen = (ti) < 4 ? ATS_KROW : ATS_VROW, plane = (ti) < 4 ? ATS_KPLANE : ATS_VPLANE;        \
+        bf16_t* dst = kvs + (buf) * ATS_BUF + (srow0 + 32 * (j & 1)) * rowlen + sch0 * 4 + 32 * (j >> 1);     \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                       \
+            unsigned d0, d1;                                                                                  \
+            sp.plane(d0, d1, p < 2);                                                                          \
+            *(uint2*)(dst + p * plane) = make_uint2(d0, d1);                                                  \
+        }                                                                                                     \
+    }
+
+    ATS_LOAD(0)
+    // Q planes (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
+    u32x4 qp[6][3];
+    {
+        const float* qptr = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) split8(*(const f32x4*)(qptr + 16 * s), *(const f32x4*)(qptr + 16 * s + 4), qp[s]);
+    }
+    ATS_WRITE(0, 0)
+    __syncthreads();
+
+    f32x16 st[8];
+    f32x16 o[3];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    // transposed-read addressing of the V planes (attention_bf16.h): inside each 16-lane group, lane 4 qq + pp supplies
+    // row qq, columns 4 pp .. 4 pp + 3
+    const int l16 = lane & 15;
+    const int tr_off = (4 * h + (l16 >> 2)) * ATS_VROW + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+        if (ti + 1 < 8) { ATS_LOAD(ti + 1) }
+        const bf16_t* T = kvs + (ti & 1) * ATS_BUF;
+        if (ti < 4) {
+            // S^T[key][query] = sum_d K[key][d] Q[query][d] for the two 32-key sub-tiles of this tile
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16_t* kp = T + (u * 32 + i) * ATS_KROW + 8 * h;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    u32x4 ka[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) ka[p] = *(const u32x4*)(kp + p * ATS_KPLANE + 16 * s);
+                    ATS_SIX(ka, qp[s], st[2 * ti + u]);
+                }
+            }
+            if (ti == 3) {
+                // softmax over the 256 keys of query q0 + i: 128 values in this lane, 128 in lane i + 32
+                float mx = st[0][0];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);   // scores arrive in log2 units
+                        st[kt][r] = p;
+                        sum += p;
+                    }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
+            }
+        } else {
+            // O[query][d] += sum over this tile's 64 keys of P[query][key] V[key][d]
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f32x16& pr = st[2 * (ti - 4) + u];
+                    u32x4 pp[3];
+                    split8(f32x4{pr[8 * s2], pr[8 * s2 + 1], pr[8 * s2 + 2], pr[8 * s2 + 3]},
+                           f32x4{pr[8 * s2 + 4], pr[8 * s2 + 5], pr[8 * s2 + 6], pr[8 * s2 + 7]}, pp);
+                    const bf16_t* vp = T + (u * 32 + 16 * s2) * ATS_VROW + tr_off;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) {
+                        u32x4 vb[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(vp + p * ATS_VPLANE + dt * 32));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                (__attribute__((address_space(3))) bf16x4*)(vp + p * ATS_VPLANE + 8 * ATS_VROW + dt * 32));
+                            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                            vb[p] = u32x4{l2.x, l2.y, h2.x, h2.y};
+                        }
+                        ATS_SIX(pp, vb, o[dt]);
+                    }
+                }
+        }
+        if (ti + 1 < 8) {
+            ATS_WRITE(ti + 1, (ti + 1) & 1)     // the other buffer: its previous tile (ti - 1) was released by the last barrier
+            __syncthreads();
+        }
+    }
+#undef ATS_LOAD
+#undef ATS_WRITE
+    // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
+        }
+}
+#undef ATS_SIX
+#undef ATS_MFMA

@@ -14,6 +14,7 @@
 
 #include "attention_f32.h"
 #include "attention_bf16.h"
+#include "attention_split.h"
 #include "common.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
@@ -131,6 +132,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_split_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GS_LDS_BYTES_OF(2));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ATS_LDS_BYTES);
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -542,7 +546,12 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
                 memset(&aa, 0, sizeof(aa));
                 for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
                 aa.nchunks = nb;
-                hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
+                // bf16x6: the split attention kernel goes with the split projections (same batch-size rule), so a small
+                // batch is computed exactly as in the f32 mode
+                if (c.compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, IEF_D, IEF_D, 1))
+                    hipLaunchKernelGGL(iefvad_attention_split_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
+                else
+                    hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
             }
             tm.end(e);
             HIP_TRY(hipGetLastError());
