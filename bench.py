@@ -231,7 +231,7 @@ def main():
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")},
             "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12,
         }
-        if a.compute == "bf16x6" and not a.no_extra_modes:
+        if world == 1 and a.compute == "bf16x6" and not a.no_extra_modes:   # N=1 only: rank 0 must not linger at N>1
             line["f32_mfma_mode"] = extra_mode(sd, margs, dev, img, ev, a, "f32")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
