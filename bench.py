@@ -227,7 +227,13 @@ def main():
                          "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "launches_per_step": launches,
                          "avg_launch_ms": gemm_ms / launches,
-                         "flops_per_launch": gemm_flops / launches},
+                         "flops_per_launch": gemm_flops / launches,
+                         "executed_mfma_flops_per_launch": gemm_flops / launches * (6.0 if a.compute == "bf16x6" else 1.0),
+                         "note": ("achieved / peak are the bf16 MFMA FLOPs the kernel executes (six bf16 multiply-adds per "
+                                  "algorithmic fp32 multiply-add of SURVEY 8d) against the dense bf16 MFMA peak; the algorithmic "
+                                  "rate is algorithmic_fp32_tflops = flops_per_launch / avg_launch_ms"
+                                  if a.compute == "bf16x6" else
+                                  "achieved = algorithmic GEMM FLOPs (SURVEY 8d) / kernel time")},
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")},
             "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12,
         }
