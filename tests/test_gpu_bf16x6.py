@@ -162,3 +162,42 @@ def test_dataset_scores_and_auc_match_the_oracle():
     r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "ucfcrime", verbose=False)
     for k in ("roc", "ap", "ano_auc"):
         assert abs(r_gpu[k] - r_cpu[k]) <= 1e-6, (k, r_gpu[k], r_cpu[k])
+
+
+def test_full_config4_batch_properties_bf16x6():
+    """BASELINE config 4 at its full single-GPU size (B = 8192 chunks = 2,097,152 snippets resident in HBM) in the
+    bench's default arithmetic, through size-independent properties: every score finite and in (0, 1); n_i + n_e = 1;
+    a duplicated chunk in another micro-batch gives bit-identical scores (same kernels, row-independent arithmetic); the
+    scores of sampled chunks agree with the fp32 MFMA mode within the fp32 gate; permuting whole micro-batches permutes
+    the scores bit for bit."""
+    sd = synth.make_state_dict(9)
+    model = make_model(sd, "bf16x6", outputs="scores")
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(1234)
+    B = 8192
+    img = torch.randn(B, 256, 768, device="cuda:0", generator=g) * 0.45
+    ev = torch.randn(B, 256, 768, device="cuda:0", generator=g) * 0.45
+    img[4097], ev[4097] = img[11], ev[11]
+    with torch.no_grad():
+        out = model(img, ev, None, None, None)
+    lg = out["logits"]
+    assert lg.shape == (B, 256, 1) and bool(torch.isfinite(lg).all())
+    assert torch.equal(lg[11], lg[4097])
+    s = torch.sigmoid(lg)
+    assert 0.0 < float(s.min()) and float(s.max()) < 1.0
+    assert float((out["w_i_mean"] + out["w_e_mean"] - 1.0).abs().max()) < 1e-5
+    # the same 64 chunks through the fp32 MFMA mode
+    pick = torch.arange(0, B, 128, device="cuda:0")
+    f32 = make_model(sd, "f32", outputs="scores")
+    with torch.no_grad():
+        ref = f32(img[pick].contiguous(), ev[pick].contiguous(), None, None, None)
+    assert float((torch.sigmoid(ref["logits"]) - s[pick]).abs().max()) <= H.TOL_SIGMOID
+    assert float((ref["logits"] - lg[pick]).abs().max()) <= H.TOL_LOGIT
+    # swap the first two 256-chunk micro-batches
+    perm = torch.cat([torch.arange(256, 512), torch.arange(0, 256), torch.arange(512, 1024)]).to("cuda:0")
+    with torch.no_grad():
+        a = model(img[:1024].contiguous(), ev[:1024].contiguous(), None, None, None)
+        b = model(img[:1024][perm].contiguous(), ev[:1024][perm].contiguous(), None, None, None)
+    assert torch.equal(a["logits"][perm], b["logits"])
+    del img, ev, out, a, b
+    torch.cuda.empty_cache()
