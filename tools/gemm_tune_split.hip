@@ -49,6 +49,10 @@ int main(int argc, char** argv) {
     for (auto& v : hA) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 1.7f;
     for (auto& v : hW) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.036f;    // ~ U(-1/sqrt(768), 1/sqrt(768))
     for (auto& v : hb) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.036f;
+    if (getenv("GS_ZERO")) {    // DVFS probe: all-zero operands toggle no multiplier bits (MI355X_MICROARCH.md, DVFS give-back)
+        for (auto& v : hA) v = 0.f;
+        for (auto& v : hW) v = 0.f;
+    }
     CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(Wf, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(bias, hb.data(), NW * 4, hipMemcpyHostToDevice));
