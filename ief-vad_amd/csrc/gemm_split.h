@@ -61,6 +61,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
@@ -82,6 +84,15 @@ struct Split4 {
             r[3] -= __builtin_bit_cast(float, d1 & 0xffff0000u);
         }
     }
+    // experiment: the same with fp16 terms (round to nearest even)
+    __device__ __forceinline__ void plane_f16(unsigned& d0, unsigned& d1, bool peel) {
+        const f16x2 a = {(_Float16)r[0], (_Float16)r[1]}, b = {(_Float16)r[2], (_Float16)r[3]};
+        d0 = __builtin_bit_cast(unsigned, a);
+        d1 = __builtin_bit_cast(unsigned, b);
+        if (peel) {
+            r[0] -= (float)a[0]; r[1] -= (float)a[1]; r[2] -= (float)b[0]; r[3] -= (float)b[1];
+        }
+    }
 };
 
 // weights -> three bf16 planes (plane stride n elements), once per iefvad_set_weights
@@ -99,14 +110,19 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
     }
 }
 
-template <int NA>
+// F16 = false: three bf16 terms per operand, six products (the production arithmetic).
+// F16 = true (EXPERIMENT, tools/gemm_tune_split only): two fp16 terms per operand (22 bits), three products
+// h1 g1 + h1 g2 + h2 g1 -- half the MFMAs, 2^-21 per product, valid only inside fp16's exponent range.
+template <int NA, bool F16 = false>
 __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* smem) {
+    constexpr int NP = F16 ? 2 : 3;                    // planes per operand
+    constexpr int NT = F16 ? 3 : 6;                    // products per multiply-add
     constexpr int BN = GS_BN_OF(NA);
     constexpr int W_PLANE = BN * 16;                   // 4-byte units: BN rows x 64 B
-    constexpr int W_SLOT = 3 * W_PLANE;
+    constexpr int W_SLOT = NP * W_PLANE;
     constexpr int W_BASE = 2 * GS_A_SLOT;
     constexpr int WROWS = BN / 4;                      // W rows staged per wave and plane
-    constexpr int NM = 6 * NA;                         // MFMAs per step (24 / 12)
+    constexpr int NM = NT * NA;                        // MFMAs per step (24 / 12)
 #ifdef GB2_CLOCK_DIAG
     const unsigned long long dg_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -141,7 +157,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     // ---- staging (LDS-DMA, lane-linear 1 KB images; the swizzle is applied to the SOURCE chunk) ----
     // A: one instruction = 8 rows x 128 B; wave w, instruction j -> rows 32 w + 8 j + (lane >> 3), chunk lane & 7
     // W: one instruction = 16 rows x 64 B; wave w, plane p, instruction j -> rows WROWS w + 16 j + (lane >> 2), chunk lane & 3
-    const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = 2 * wplane + (int)((BN - 1) * K + K) * 2;
+    const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = (NP - 1) * wplane + (int)((BN - 1) * K + K) * 2;
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0, nrecA, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0, nrecW, 0x00020000);
     const int arow = lane >> 3, achk = lane & 7;
@@ -160,7 +176,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     auto stage_w = [&](int tile, int slot) {
         float* Wd = smem + W_BASE + slot * W_SLOT + uwave * WROWS * 16;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int j = 0; j < WROWS / 16; ++j)
                 GLDS16(rsW, voW, p * wplane + ((uwave * WROWS + j * 16) * K + tile * GS_BK) * 2, Wd + p * W_PLANE + j * 16 * 16);
@@ -178,21 +194,26 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ap[NA][3], an[NA][3];                        // bf16 planes of the A fragments: current k-tile / next k-tile
+    u32x4 ap[NA][NP], an[NA][NP];                      // planes of the A fragments: current k-tile / next k-tile
     auto mfma_row = [&](int b, int pa, const u32x4& wv) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
-            acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[a][pa]),
-                                                                  __builtin_bit_cast(bf16x8, wv), acc16[a][b], 0, 0, 0);
+        for (int a = 0; a < NA; ++a) {
+            if constexpr (F16)
+                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[a][pa]),
+                                                                     __builtin_bit_cast(f16x8, wv), acc16[a][b], 0, 0, 0);
+            else
+                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[a][pa]),
+                                                                      __builtin_bit_cast(bf16x8, wv), acc16[a][b], 0, 0, 0);
+        }
     };
     // half `hf` (k = 8q + 4 (hf & 1) .. + 3) of row-tile (hf >> 1) of the NEXT k-tile: fp32 fragment -> three planes
     auto split_half = [&](int hf, const f32x4& v) {
         Split4 sp;
         sp.r = v;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             unsigned d0, d1;
-            sp.plane(d0, d1, p < 2);
+            if constexpr (F16) sp.plane_f16(d0, d1, p < NP - 1); else sp.plane(d0, d1, p < NP - 1);
             an[hf >> 1][p][2 * (hf & 1)] = d0;
             an[hf >> 1][p][2 * (hf & 1) + 1] = d1;
         }
@@ -212,7 +233,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];
+        for (int p = 0; p < NP; ++p) ap[a][p] = an[a][p];
 #ifdef GB2_CLOCK_DIAG
     const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_last = dg_c0, dg_acc[3] = {0, 0, 0};   // cycles in: MFMA body | vmcnt + lgkmcnt wait | barrier
@@ -245,25 +266,25 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
             if (d < 4) {
                 GLDS16(rA, voA[d & 1], (uwave * 32 + d * 8) * lda * 4 + kA, Ad + d * 8 * 32);
             } else {
-                const int p = (d - 4) / (WROWS / 16), j = (d - 4) % (WROWS / 16);
+                const int p = (d - 4) / (WROWS / 16), j = (d - 4) % (WROWS / 16);      /* d - 4 < NP WROWS / 16 */
                 GLDS16(rW, voW, p * wplane + (uwave * WROWS + j * 16) * K * 2 + kW, Wd + p * W_PLANE + j * 16 * 16);
             }
         };
         const float* Wv = smem + W_BASE + (kt & 1) * W_SLOT + b_of;
         const float* Av = smem + ((kt + 1) & 1) * GS_A_SLOT;
         auto a_half = [&](int hf) { return *(const f32x4*)(Av + (hf >> 1) * 16 * 32 + ((hf & 1) ? a_hi : a_lo)); };
-        u32x4 w[3];
+        u32x4 w[NP];
         f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = *(const u32x4*)(Wv + p * W_PLANE);
+        for (int p = 0; p < NP; ++p) w[p] = *(const u32x4*)(Wv + p * W_PLANE);
         v0 = a_half(0);
         GS_FENCE();
         // (B and g are literals below: sched_group_barrier takes integer constant expressions only)
 #define GS_NSPLIT(B) (NA == 4 ? ((B) < 6 ? 1 : (B) == 6 ? 2 : 0) : ((B) < 4 ? 1 : 0))       /* half-fragments split in step B */
 #define GS_NAREAD(B) ((B) < 7 ? GS_NSPLIT((B) + 1) : 0)                                      /* fp32 A reads for step B+1 */
-#define GS_NREAD(B) (((B) < 7 ? 3 : 0) + GS_NAREAD(B))
-#define GS_NDMA(B) (NA == 4 ? ((B) < 4 ? 4 : 0) : ((B) < 5 ? 2 : 0))
-#define GS_NVALU(B) ((B) == 7 ? 12 * NA : GS_EXP_NOSPLIT ? 0 : 22 * GS_NSPLIT(B))
+#define GS_NREAD(B) (((B) < 7 ? NP : 0) + GS_NAREAD(B))
+#define GS_NDMA(B) (NA == 4 ? ((B) < 4 ? (F16 ? 3 : 4) : 0) : (F16 ? ((B) < 4 ? 2 : 0) : ((B) < 5 ? 2 : 0)))
+#define GS_NVALU(B) ((B) == 7 ? 4 * NP * NA : GS_EXP_NOSPLIT ? 0 : (F16 ? 20 : 22) * GS_NSPLIT(B))
 #define GS_VSLOT(B, g) (((g) + 1) * GS_NVALU(B) / NM - (g) * GS_NVALU(B) / NM)
 #define GS_SLOT(B, g)                                                                                           \
         if ((g) < NM) {                                                                                         \
@@ -273,16 +294,18 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
         }
 #define GS_STEP(B)                                                                                              \
         {                                                                                                       \
-            u32x4 wn[3];                                                                                        \
+            u32x4 wn[NP];                                                                                       \
             f32x4 vn0 = {0.f, 0.f, 0.f, 0.f}, vn1 = {0.f, 0.f, 0.f, 0.f};                                       \
             if ((B) < 7) {                                                                                      \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(Wv + p * W_PLANE + ((B) + 1) * 16 * 16); \
+                _Pragma("unroll") for (int p = 0; p < NP; ++p) wn[p] = *(const u32x4*)(Wv + p * W_PLANE + ((B) + 1) * 16 * 16); \
                 if (GS_NAREAD(B) == 1) vn0 = a_half((B) + 1);                                                   \
                 if (GS_NAREAD(B) == 2) { vn0 = a_half((B) + 1); vn1 = a_half((B) + 2); }                        \
             }                                                                                                   \
-            mfma_row(B, 2, w[0]);      /* a3 w1 */                                                              \
-            mfma_row(B, 0, w[2]);      /* a1 w3 */                                                              \
-            mfma_row(B, 1, w[1]);      /* a2 w2 */                                                              \
+            if constexpr (!F16) {                                                                               \
+                mfma_row(B, NP - 1, w[0]);      /* a3 w1 */                                                     \
+                mfma_row(B, 0, w[NP - 1]);      /* a1 w3 */                                                     \
+                mfma_row(B, 1, w[1]);           /* a2 w2 */                                                     \
+            }                                                                                                   \
             mfma_row(B, 1, w[0]);      /* a2 w1 */                                                              \
             mfma_row(B, 0, w[1]);      /* a1 w2 */                                                              \
             mfma_row(B, 0, w[0]);      /* a1 w1 */                                                              \
@@ -292,7 +315,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
             }                                                                                                   \
             if ((B) == 7) {                                                                                     \
                 _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                  \
-                    _Pragma("unroll") for (int p = 0; p < 3; ++p) ap[a][p] = an[a][p];                          \
+                    _Pragma("unroll") for (int p = 0; p < NP; ++p) ap[a][p] = an[a][p];                         \
             }                                                                                                   \
             _Pragma("unroll") for (int d = 0; d < GS_NDMA(B); ++d) dma(GS_NDMA(B) * (B) + d);                   \
             if (GS_NREAD(B) > 0) __builtin_amdgcn_sched_group_barrier(0x100, GS_NREAD(B) > 0 ? GS_NREAD(B) : 1, 0); \
@@ -302,7 +325,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
             GS_SLOT(B, 18) GS_SLOT(B, 19) GS_SLOT(B, 20) GS_SLOT(B, 21) GS_SLOT(B, 22) GS_SLOT(B, 23)           \
             GS_FENCE();                                                                                         \
             if ((B) < 7) {                                                                                      \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) w[p] = wn[p];                                     \
+                _Pragma("unroll") for (int p = 0; p < NP; ++p) w[p] = wn[p];                                    \
                 if (GS_NAREAD(B) >= 1) v0 = vn0;                                                                \
                 if (GS_NAREAD(B) == 2) v1 = vn1;                                                                \
             }                                                                                                   \
@@ -359,3 +382,14 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_split_n128_kernel(GemmBArg
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_split_body<2>(args, smem);
 }
+
+#ifdef GS_EXPERIMENT_F16     // tools/gemm_tune_split only
+__global__ __launch_bounds__(256, 1) void iefvad_gemm_split_f16_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_split_body<4, true>(args, smem);
+}
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_split_f16_n128_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_split_body<2, true>(args, smem);
+}
+#endif

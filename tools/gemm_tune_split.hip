@@ -7,6 +7,7 @@
 #include <vector>
 #include <algorithm>
 #include <math.h>
+#define GS_EXPERIMENT_F16
 #include "../ief-vad_amd/csrc/gemm_split.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -18,9 +19,11 @@ static float bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; m
 
 struct Variant { const char* name; int kind; int epi; bool c32; };
 
+static GemmBArgs gh;   // fp16 two-term experiment: same A, W as two fp16 planes
 static float run(const Variant& v, GemmBArgs gs, GemmBArgs gf, int iters) {
-    gs.epi = gf.epi = v.epi; gs.alpha = gf.alpha = 0.5f;
-    if (!v.c32) { gs.p[0].C = gf.p[0].C = nullptr; }
+    gs.epi = gf.epi = gh.epi = v.epi; gs.alpha = gf.alpha = gh.alpha = 0.5f;
+    gh.p[0].C = gs.p[0].C;
+    if (!v.c32) { gs.p[0].C = gf.p[0].C = gh.p[0].C = nullptr; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
     for (int it = 0; it < iters; ++it) {
@@ -28,6 +31,8 @@ static float run(const Variant& v, GemmBArgs gs, GemmBArgs gf, int iters) {
         dim3 grid2((gs.M / GS_BM) * (gs.N / 128), 1, 1);
         if (v.kind == 0) hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, 0, gs);
         else if (v.kind == 2) hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid2, dim3(256), GS_LDS_BYTES_OF(2), 0, gs);
+        else if (v.kind == 3) hipLaunchKernelGGL(iefvad_gemm_split_f16_kernel, grid, dim3(256), GS_LDS_BYTES, 0, gh);
+        else if (v.kind == 4) hipLaunchKernelGGL(iefvad_gemm_split_f16_n128_kernel, grid2, dim3(256), GS_LDS_BYTES_OF(2), 0, gh);
         else hipLaunchKernelGGL(iefvad_gemm_f32_t256_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, gf);
     }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -59,6 +64,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(R, 0, (size_t)M * NW * 4));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES_OF(2)));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_split_f16_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES_OF(2)));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     for (int ni = 0; ni < 2; ++ni) {
         const int N = Ns[ni];
@@ -76,6 +83,18 @@ int main(int argc, char** argv) {
         gs.M = M; gs.N = N; gs.K = K; gs.lda = K; gs.ldc = N; gs.wplane = N * K * 2;
         gs.p[0].A = (const bf16_t*)A; gs.p[0].W = Wp; gs.p[0].bias = bias; gs.p[0].C = C; gs.p[0].R = R; gs.p[1] = gs.p[0];
         GemmBArgs gf = gs; gf.p[0].W = (const bf16_t*)Wf; gf.p[1] = gf.p[0];
+        {   // two fp16 planes of W (round to nearest even), plane stride N*K
+            std::vector<_Float16> hh((size_t)2 * N * K);
+            for (size_t q = 0; q < (size_t)N * K; ++q) {
+                const float x = hW[q];
+                const _Float16 h1 = (_Float16)x;
+                hh[q] = h1; hh[(size_t)N * K + q] = (_Float16)(x - (float)h1);
+            }
+            static _Float16* Wh = nullptr;
+            if (!Wh) CK(hipMalloc(&Wh, (size_t)2 * NW * K * 2));
+            CK(hipMemcpy(Wh, hh.data(), hh.size() * 2, hipMemcpyHostToDevice));
+            gh = gs; gh.p[0].W = (const bf16_t*)Wh; gh.p[1] = gh.p[0];
+        }
         // accuracy against a double-precision dot product on sampled outputs
         std::vector<float> cs((size_t)M * N), cf((size_t)M * N);
         const Variant vs0 = {"split", 0, EPI_BIAS, true}, vf0 = {"f32", 1, EPI_BIAS, true};
@@ -99,8 +118,24 @@ int main(int argc, char** argv) {
         }
         printf("N=%d accuracy vs fp64 on %zu sampled outputs: split max %.3g rms %.3g | fp32 MFMA max %.3g rms %.3g | split vs fp32 MFMA max %.3g\n",
                N, cnt, es, sqrt(ss / cnt), ef, sqrt(sf / cnt), md);
+        {   // fp16 two-term experiment: accuracy of the same sampled outputs
+            const Variant vh = {"f16x3 n128", 4, EPI_BIAS, true};
+            std::vector<float> ch((size_t)M * N);
+            CK(hipMemset(C, 0, ch.size() * 4)); run(vh, gs, gf, 1); CK(hipMemcpy(ch.data(), C, ch.size() * 4, hipMemcpyDeviceToHost));
+            double eh = 0, sh = 0; size_t c2 = 0;
+            for (int m = 0; m < M; m += 37)
+                for (int n = 0; n < N; n += 5) {
+                    double d = hb[n];
+                    for (int k = 0; k < K; ++k) d += (double)hA[(size_t)m * K + k] * (double)hW[(size_t)n * K + k];
+                    const double a = fabs(ch[(size_t)m * N + n] - d);
+                    eh = std::max(eh, a); sh += a * a; ++c2;
+                }
+            printf("N=%d fp16 two-term / three-product experiment: max %.3g rms %.3g\n", N, eh, sqrt(sh / c2));
+        }
         const Variant vs[] = {{"split bias C32", 0, EPI_BIAS, true}, {"split refine C32", 0, EPI_REFINE, true}, {"split none", 0, EPI_BIAS, false},
                               {"n128  bias C32", 2, EPI_BIAS, true}, {"n128  refine C32", 2, EPI_REFINE, true}, {"n128  none", 2, EPI_BIAS, false},
+                              {"f16x3 256 bias C32", 3, EPI_BIAS, true}, {"f16x3 256 refine", 3, EPI_REFINE, true}, {"f16x3 256 none", 3, EPI_BIAS, false},
+                              {"f16x3 128 bias C32", 4, EPI_BIAS, true}, {"f16x3 128 refine", 4, EPI_REFINE, true}, {"f16x3 128 none", 4, EPI_BIAS, false},
                               {"f32   bias C32", 1, EPI_BIAS, true}, {"f32   refine C32", 1, EPI_REFINE, true}, {"f32   none", 1, EPI_BIAS, false}};
         const int nv = sizeof(vs) / sizeof(vs[0]);
         std::vector<std::vector<float>> t(nv);
