@@ -55,7 +55,7 @@ def parse():
     p.add_argument("--chunks", type=int, default=8192, help="chunks [256,768] per GPU per step")
     p.add_argument("--micro-batch", type=int, default=0, help="chunks per internal pass (0 = library default)")
     p.add_argument("--outputs", default="scores", choices=["scores", "full"])
-    p.add_argument("--compute", default="bf16x6", choices=["f32", "bf16", "bf16x6"],
+    p.add_argument("--compute", default="bf16x6", choices=["f32", "bf16", "bf16x6", "fp16x3"],
                    help="arithmetic of the dense projections: bf16x6 (default) = fp32-accurate, six bf16 MFMA products of the "
                         "exact 3-term split of each fp32 operand, fp32 accumulation (held to the f32 mode's parity gates); "
                         "f32 = fp32 MFMA; bf16 = bf16-rounded operands (reduced precision, BASELINE config 3)")
@@ -204,11 +204,13 @@ def main():
                              .get(a.compute, "none"))
         peak = PEAK_F32_MFMA_TFLOPS if a.compute == "f32" else PEAK_BF16_MFMA_TFLOPS
         # bf16x6: each algorithmic (fp32) multiply-add is executed as six bf16 MFMA multiply-adds
-        executed = achieved * (6.0 if a.compute == "bf16x6" else 1.0)
+        executed = achieved * {"bf16x6": 6.0, "fp16x3": 3.0}.get(a.compute, 1.0)
         kernel = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_kernel",
-                  "bf16x6": "iefvad_gemm_split_n128_kernel"}[a.compute]
+                  "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}[a.compute]
         dtype = {"f32": "f32", "bf16": "bf16",
-                 "bf16x6": "f32 emulated: exact 3-term bf16 split of both fp32 operands, 6 bf16 MFMA products, fp32 accumulate"}[a.compute]
+                 "bf16x6": "f32 emulated: exact 3-term bf16 split of both fp32 operands, 6 bf16 MFMA products, fp32 accumulate",
+                 "fp16x3": "near-f32 (22-bit products): 2-term fp16 split of both scaled fp32 operands, 3 fp16 MFMA products, "
+                           "fp32 accumulate"}[a.compute]
         if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256:
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         line = {
@@ -228,7 +230,7 @@ def main():
                          "launches_per_step": launches,
                          "avg_launch_ms": gemm_ms / launches,
                          "flops_per_launch": gemm_flops / launches,
-                         "executed_mfma_flops_per_launch": gemm_flops / launches * (6.0 if a.compute == "bf16x6" else 1.0),
+                         "executed_mfma_flops_per_launch": gemm_flops / launches * {"bf16x6": 6.0, "fp16x3": 3.0}.get(a.compute, 1.0),
                          "note": ("achieved / peak are the bf16 MFMA FLOPs the kernel executes (six bf16 multiply-adds per "
                                   "algorithmic fp32 multiply-add of SURVEY 8d) against the dense bf16 MFMA peak; the algorithmic "
                                   "rate is algorithmic_fp32_tflops = flops_per_launch / avg_launch_ms"

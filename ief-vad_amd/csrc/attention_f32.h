@@ -21,6 +21,7 @@ struct AttnArgs {
     float* out[2];         // [N, 768] per modality: concat over heads (fp32), or
     __bf16* outb[2];       // the same as bf16 when non-null (A operand of a bf16 out_proj)
     int nchunks;           // chunks per modality in this launch
+    float* amax[2];        // fp16x3 mode (attention_split.h only): running max |out| per modality, nullable
 };
 
 #define ATT_LDK 100

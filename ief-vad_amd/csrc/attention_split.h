@@ -189,13 +189,16 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
 #undef ATS_LOAD
 #undef ATS_WRITE
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
+    float om = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
+            om = fmaxf(om, fabsf(o[dt][r]));
         }
+    if (args.amax[mod]) amax_publish(args.amax[mod], wave_max(om), lane);
 }
 #undef ATS_SIX
 #undef ATS_MFMA

@@ -25,3 +25,36 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Running maximum of |x| over a tensor (fp16x3 mode: the power-of-two operand scale of the next projection), kept in
+// IEF_AMAX_WAYS device words: a producer workgroup updates word (blockIdx.x % WAYS) -- one hot word would serialise the
+// 10^5 waves of a row-wise kernel -- and the consumer takes the maximum of all of them.  Non-negative floats order like
+// their bit patterns, so the update is an unsigned atomicMax; the word is read first and the atomic skipped when it would
+// not grow (after the first few workgroups it rarely does).  NaNs are ignored by fmaxf upstream.
+#define IEF_AMAX_WAYS 32
+#define IEF_AMAX_STRIDE 32          // floats between the words of one tensor: one 128-byte line each
+#define IEF_AMAX_FLOATS (IEF_AMAX_WAYS * IEF_AMAX_STRIDE)
+__device__ __forceinline__ void amax_publish(float* slot, float wave_amax, int lane) {
+    if (lane == 0) {
+        float* word = slot + (blockIdx.x % IEF_AMAX_WAYS) * IEF_AMAX_STRIDE;
+        const unsigned b = __float_as_uint(wave_amax);
+        if (b > *(volatile unsigned*)word) atomicMax((unsigned*)word, b);
+    }
+}
+__device__ __forceinline__ float amax_read(const float* slot) {
+    const int lane = threadIdx.x & 63;
+    return wave_max(lane < IEF_AMAX_WAYS ? slot[lane * IEF_AMAX_STRIDE] : 0.f);
+}
+
+// floor(log2(amax)) for a finite positive amax; 13 (scale 2^0 below) for zero / non-finite
+__device__ __forceinline__ int amax_exponent(float amax) {
+    const unsigned b = __float_as_uint(amax);
+    const int e = (int)((b >> 23) & 0xff);
+    return (e == 0 || e == 0xff) ? 13 : e - 127;
+}

@@ -35,6 +35,11 @@ struct GemmBProblem {
     bf16_t* Cb;          // [M, ldc] bf16 copy of the result, nullable
     const float* R;      // residual, fp32, same layout as C
     float* C2;           // EPI_HEADS second output (fp32, [M, 768])
+    // fp16x3 mode (gemm_split.h, F16 path): running max |.| words of the A tensor, of the W matrix (both read) and of the
+    // result written to C (updated), nullable
+    const float* amaxA;
+    const float* amaxW;
+    float* amaxC;
 };
 
 struct GemmBArgs {
@@ -239,10 +244,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // re-reads them row-wise, so bias / residual loads and stores are 16 bytes per lane and 512-byte row segments per
 // instruction.  MF16 selects the accumulator map (16x16 tiles in acc16, else 32x32 tiles in acc).
 // The wave tile is (32 PASSES) rows x 128 columns with origin (wrow0, wcol0) inside the block tile at (m0, n0).
+// `cscale` multiplies the accumulators before the bias (1 except in the fp16x3 path, where it undoes the operand scales);
+// `amax_out` (nullable) receives the running max |value written to C|.
 template <bool MF16, int PASSES>
 __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
                                                    int wrow0, int wcol0, f32x16 (&acc)[PASSES][4],
-                                                   f32x4 (&acc16)[2 * PASSES][8]) {
+                                                   f32x4 (&acc16)[2 * PASSES][8], float cscale = 1.0f, float* amax_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int r16 = lane & 15, q16 = lane >> 4;
@@ -261,6 +268,7 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
     f32x4 scale = {1.f, 1.f, 1.f, 1.f};
     if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
     if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
+    float vmax = 0.f;
 #pragma unroll
     for (int a = 0; a < PASSES; ++a) {
         const int mrow = m0 + wrow0 + a * 32 + rq;
@@ -288,7 +296,7 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             f32x4 v = *(const f32x4*)(E + (rq + 2 * u) * GB2_EPI_LD + 4 * cq);
-            v = v + bv;
+            v = v * cscale + bv;
             if (epi == EPI_QKV) v = v * scale;
             else if (epi == EPI_BIAS_RELU) {
 #pragma unroll
@@ -303,8 +311,13 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
                 for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
                 *(bf16x4*)(C16 + o) = w;
             }
+            if (amax_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+            }
         }
     }
+    if (amax_out) amax_publish(amax_out, wave_max(vmax), lane);
 }
 
 // the 2 x 2 wave layout of the 128 x 256 kernels: wave (wr, wc) owns the 64 x 128 tile at (64 wr, 128 wc)

@@ -111,8 +111,12 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
 }
 
 // F16 = false: three bf16 terms per operand, six products (the production arithmetic).
-// F16 = true (EXPERIMENT, tools/gemm_tune_split only): two fp16 terms per operand (22 bits), three products
-// h1 g1 + h1 g2 + h2 g1 -- half the MFMAs, 2^-21 per product, valid only inside fp16's exponent range.
+// F16 = true (compute = fp16x3, opt-in): two fp16 terms per operand (22 bits), three products h1 g1 + h1 g2 + h2 g1 --
+// half the MFMAs, 2^-21 per product.  fp16 has a 5-bit exponent, so both operands are scaled by powers of two (exact):
+// A by 2^(13 - floor(log2 amaxA)) from the running max |A| word its producer kernel maintained (P.amaxA), W at
+// iefvad_set_weights by the same rule (P.amaxW); the epilogue multiplies the accumulators by the inverse (cscale).
+// Scaled maxima sit in [2^13, 2^14); elements more than 2^27 below their tensor's maximum fall into fp16's subnormals
+// (absolute error <= 2^-38 of the maximum).  Null amax pointers (tools/gemm_tune_split) mean unscaled operands.
 template <int NA, bool F16 = false>
 __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* smem) {
     constexpr int NP = F16 ? 2 : 3;                    // planes per operand
@@ -145,7 +149,15 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     }
     const int m0 = tm * GS_BM, n0 = tn * BN;
     const int K = args.K, lda = args.lda;
-    const int wplane = args.wplane;                    // bytes between the bf16 planes of W
+    const int wplane = args.wplane;                    // bytes between the planes of W
+    float ascale = 1.0f, cscale = 1.0f;                // fp16x3: operand scale of A, inverse of both scales
+    if constexpr (F16) {
+        if (P.amaxA && P.amaxW) {
+            const int ea = 13 - amax_exponent(amax_read(P.amaxA)), ew = 13 - amax_exponent(amax_read(P.amaxW));
+            ascale = __builtin_ldexpf(1.0f, ea);
+            cscale = __builtin_ldexpf(1.0f, -ea - ew);
+        }
+    }
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -209,7 +221,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     // half `hf` (k = 8q + 4 (hf & 1) .. + 3) of row-tile (hf >> 1) of the NEXT k-tile: fp32 fragment -> three planes
     auto split_half = [&](int hf, const f32x4& v) {
         Split4 sp;
-        sp.r = v;
+        if constexpr (F16) sp.r = v * ascale; else sp.r = v;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             unsigned d0, d1;
@@ -284,7 +296,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
 #define GS_NAREAD(B) ((B) < 7 ? GS_NSPLIT((B) + 1) : 0)                                      /* fp32 A reads for step B+1 */
 #define GS_NREAD(B) (((B) < 7 ? NP : 0) + GS_NAREAD(B))
 #define GS_NDMA(B) (NA == 4 ? ((B) < 4 ? (F16 ? 3 : 4) : 0) : (F16 ? ((B) < 4 ? 2 : 0) : ((B) < 5 ? 2 : 0)))
-#define GS_NVALU(B) ((B) == 7 ? 4 * NP * NA : GS_EXP_NOSPLIT ? 0 : (F16 ? 20 : 22) * GS_NSPLIT(B))
+#define GS_NVALU(B) ((B) == 7 ? 4 * NP * NA : GS_EXP_NOSPLIT ? 0 : (F16 ? 24 : 22) * GS_NSPLIT(B))
 #define GS_VSLOT(B, g) (((g) + 1) * GS_NVALU(B) / NM - (g) * GS_NVALU(B) / NM)
 #define GS_SLOT(B, g)                                                                                           \
         if ((g) < NM) {                                                                                         \
@@ -361,7 +373,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
 #undef GLDS16
     // (the last tile ended with lgkmcnt(0) + barrier: the ring is dead, the epilogue image may overwrite it)
     f32x16 unused[NA / 2][4];
-    gemm_wave_epilogue<true, NA / 2>(args, P, smem, m0, n0, wrow0, wcol0, unused, acc16);
+    gemm_wave_epilogue<true, NA / 2>(args, P, smem, m0, n0, wrow0, wcol0, unused, acc16, cscale, F16 ? P.amaxC : nullptr);
 #ifdef GB2_CLOCK_DIAG
     if (threadIdx.x == 0 && P.C2) {
         unsigned long long* dy = (unsigned long long*)P.C2 + 5 * gridDim.x * gridDim.z + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
@@ -383,13 +395,33 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_split_n128_kernel(GemmBArg
     gemm_split_body<2>(args, smem);
 }
 
+// fp16x3 (opt-in): 128 x 128, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_split_f16_n128_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_split_body<2, true>(args, smem);
+}
+
 #ifdef GS_EXPERIMENT_F16     // tools/gemm_tune_split only
 __global__ __launch_bounds__(256, 1) void iefvad_gemm_split_f16_kernel(GemmBArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_split_body<4, true>(args, smem);
 }
-__global__ __launch_bounds__(256, 2) void iefvad_gemm_split_f16_n128_kernel(GemmBArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_split_body<2, true>(args, smem);
-}
 #endif
+
+// weights -> two fp16 planes scaled by 2^(13 - floor(log2 max|W|)) (plane stride n elements); `amax` was filled by
+// iefvad_amax_kernel over the same matrix
+__global__ __launch_bounds__(256) void iefvad_split_planes_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ planes,
+                                                                      size_t n, const float* __restrict__ amax) {
+    const float scale = __builtin_ldexpf(1.0f, 13 - amax_exponent(amax_read(amax)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        Split4 s;
+        s.r = *(const f32x4*)(src + i) * scale;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            unsigned d0, d1;
+            s.plane_f16(d0, d1, p < 1);
+            *(uint2*)(planes + (size_t)p * n + i) = make_uint2(d0, d1);
+        }
+    }
+}

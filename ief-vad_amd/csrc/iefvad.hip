@@ -81,7 +81,18 @@ struct iefvad_handle {
     bf16_t* head_ws[2];
     bf16_t* ref_w1s[IEFVAD_MAX_STEPS];
     bf16_t* ref_w2s[IEFVAD_MAX_STEPS];
+    // IEFVAD_COMPUTE_FP16X3: two scaled fp16 planes [2][N][768] per projection matrix, the running-max words of the
+    // matrices ([0, kAmaxActBase) of amax_dev, filled at set_weights) and of the activations of the current micro-batch
+    _Float16* arena_h;
+    float* amax_dev;
+    _Float16* in_wh[2][IEFVAD_MAX_LAYERS];  const float* in_wa[2][IEFVAD_MAX_LAYERS];
+    _Float16* out_wh[2][IEFVAD_MAX_LAYERS]; const float* out_wa[2][IEFVAD_MAX_LAYERS];
+    _Float16* head_wh[2];                   const float* head_wa[2];
+    _Float16* ref_w1h[IEFVAD_MAX_STEPS];    const float* ref_w1a[IEFVAD_MAX_STEPS];
+    _Float16* ref_w2h[IEFVAD_MAX_STEPS];    const float* ref_w2a[IEFVAD_MAX_STEPS];
 };
+static const int kAmaxTensors = 512, kAmaxActBase = 256;   // tensors with a running max: [0, 256) matrices, [256, 512) activations
+static const int kAmaxWords = kAmaxTensors * IEF_AMAX_FLOATS;
 
 // chunks per internal pass: 256 (65,536 rows, 2.8 GB of workspace) in fp32 mode; the bf16 kernels are ~100 us
 // each at that size and gain another 7 % from 4x longer launches (1024 chunks, 11 GB of workspace)
@@ -111,7 +122,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         return fail("iefvad_create: num_steps %d outside 0..%d", cfg->num_steps, IEFVAD_MAX_STEPS);
     if (cfg->noise_model != IEFVAD_NOISE_GAUSSIAN && cfg->noise_model != IEFVAD_NOISE_STUDENT_T)
         return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");   // imf_vad.py:138
-    if (cfg->compute != IEFVAD_COMPUTE_F32 && cfg->compute != IEFVAD_COMPUTE_BF16 && cfg->compute != IEFVAD_COMPUTE_BF16X6)
+    if (cfg->compute != IEFVAD_COMPUTE_F32 && cfg->compute != IEFVAD_COMPUTE_BF16 && cfg->compute != IEFVAD_COMPUTE_BF16X6 &&
+        cfg->compute != IEFVAD_COMPUTE_FP16X3)
         return fail("iefvad_create: unknown compute mode %d", cfg->compute);
     if (cfg->noise_model == IEFVAD_NOISE_STUDENT_T && !(cfg->nu != 0.f))
         return fail("iefvad_create: nu must be non-zero for StudentT");
@@ -135,6 +147,10 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_f16_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GS_LDS_BYTES_OF(2));
+    if (e == hipSuccess && cfg->compute == IEFVAD_COMPUTE_FP16X3) e = hipMalloc((void**)&h->amax_dev, kAmaxWords * sizeof(float));
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -148,6 +164,8 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->arena_b) (void)hipFree(h->arena_b);
     if (h->arena_s) (void)hipFree(h->arena_s);
+    if (h->arena_h) (void)hipFree(h->arena_h);
+    if (h->amax_dev) (void)hipFree(h->amax_dev);
     delete h;
 }
 
@@ -279,6 +297,39 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
             if (int rc = split(&h->ref_w2s[k], h->ref_w2[k], DD)) return rc;
         }
     }
+    if (h->cfg.compute == IEFVAD_COMPUTE_FP16X3) {
+        // two fp16 planes per projection matrix, scaled by a power of two from the matrix's max |w| (gemm_split.h, F16)
+        const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
+        if (!h->arena_h) HIP_TRY(hipMalloc((void**)&h->arena_h, 2 * nb * sizeof(_Float16)));
+        HIP_TRY(hipMemsetAsync(h->amax_dev, 0, kAmaxActBase * IEF_AMAX_FLOATS * sizeof(float), stream));
+        _Float16* q = h->arena_h;
+        int widx = 0;
+        auto split = [&](_Float16** dst, const float** amax, const float* src, size_t n) -> int {
+            if (widx >= kAmaxActBase) return fail("iefvad_set_weights: too many projection matrices");
+            *dst = q;
+            q += 2 * n;
+            float* word = h->amax_dev + IEF_AMAX_FLOATS * widx++;
+            *amax = word;
+            size_t blocks = (n / 4 + 255) / 256;
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(iefvad_amax_kernel, dim3((unsigned)blocks, 1), dim3(256), 0, stream, src, src, word, word, n);
+            hipLaunchKernelGGL(iefvad_split_planes_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, *dst, n,
+                               (const float*)word);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        for (int m = 0; m < 2; ++m) {
+            for (int l = 0; l < L; ++l) {
+                if (int rc = split(&h->in_wh[m][l], &h->in_wa[m][l], h->in_w[m][l], 3 * DD)) return rc;
+                if (int rc = split(&h->out_wh[m][l], &h->out_wa[m][l], h->out_w[m][l], DD)) return rc;
+            }
+            if (int rc = split(&h->head_wh[m], &h->head_wa[m], h->head_w[m], 2 * DD)) return rc;
+        }
+        for (int k = 0; k < K; ++k) {
+            if (int rc = split(&h->ref_w1h[k], &h->ref_w1a[k], h->ref_w1[k], DD)) return rc;
+            if (int rc = split(&h->ref_w2h[k], &h->ref_w2a[k], h->ref_w2[k], DD)) return rc;
+        }
+    }
     h->weights_set = true;
     return 0;
 }
@@ -383,12 +434,13 @@ static bool split_eligible(int M, int N, int K, int nz) {
     return M % GS_BM == 0 && N % kSplitBN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / kSplitBN) * nz >= 512;
 }
 
-static int launch_gemm_split(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
+static int launch_gemm_split(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage, bool f16 = false) {
     if (a.M % GS_BM || a.N % kSplitBN || a.K % 64 || a.K < 64)
         return fail("gemm(bf16x6): shape M=%d N=%d K=%d not a multiple of the %dx%dx64 tile", a.M, a.N, a.K, GS_BM, kSplitBN);
     dim3 grid((a.M / GS_BM) * (a.N / kSplitBN), 1, nz);
     hipEvent_t e = tm.begin(stage);
-    hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), stream, a);
+    if (f16) hipLaunchKernelGGL(iefvad_gemm_split_f16_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), stream, a);
+    else hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), stream, a);
     tm.end(e);
     tm.gemm_launches += 1;
     HIP_TRY(hipGetLastError());
@@ -404,6 +456,10 @@ struct Proj {
     const float* W32[2];
     const bf16_t* W16[2];
     const bf16_t* Ws[2];      // three-plane split of W (IEFVAD_COMPUTE_BF16X6)
+    const _Float16* Wh[2];    // two scaled fp16 planes of W + the running-max words (IEFVAD_COMPUTE_FP16X3)
+    const float* amaxW[2];
+    const float* amaxA[2];
+    float* amaxC[2];
     const float* bias[2];
     float* C[2];              // fp32 result (nullable in bf16 mode)
     bf16_t* Cb[2];            // bf16 copy of the result (bf16 mode only, nullable)
@@ -414,18 +470,24 @@ struct Proj {
     int qcols;
 };
 
-static int launch_proj(const Proj& p, int compute, int rows, hipStream_t stream, Timer& tm, int stage) {
+static int launch_proj(const Proj& p, int compute, bool use_split, int rows, hipStream_t stream, Timer& tm, int stage) {
     const bool bf16 = (compute == IEFVAD_COMPUTE_BF16);
-    if (compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, p.N, IEF_D, p.nz)) {
+    if (use_split) {   // one rule for every projection of a micro-batch: the 768-wide, single-problem grid fills the chip
+        const bool f16 = (compute == IEFVAD_COMPUTE_FP16X3);
         GemmBArgs g;
         memset(&g, 0, sizeof(g));
         g.M = rows; g.N = p.N; g.K = IEF_D; g.lda = IEF_D; g.ldc = p.ldc; g.epi = p.epi; g.alpha = p.alpha; g.qcols = p.qcols;
         g.wplane = p.N * IEF_D * 2;
         for (int m = 0; m < p.nz; ++m) {
             g.p[m].A = (const bf16_t*)p.A32[m];          // fp32 data behind the typed pointer
-            g.p[m].W = p.Ws[m]; g.p[m].bias = p.bias[m]; g.p[m].C = p.C[m]; g.p[m].R = p.R[m]; g.p[m].C2 = p.C2[m];
+            g.p[m].W = f16 ? (const bf16_t*)p.Wh[m] : p.Ws[m];
+            g.p[m].bias = p.bias[m]; g.p[m].C = p.C[m]; g.p[m].R = p.R[m]; g.p[m].C2 = p.C2[m];
+            if (f16) {
+                if (!p.amaxA[m] || !p.amaxW[m]) return fail("gemm(fp16x3): missing running-max word");
+                g.p[m].amaxA = p.amaxA[m]; g.p[m].amaxW = p.amaxW[m]; g.p[m].amaxC = p.amaxC[m];
+            }
         }
-        return launch_gemm_split(g, p.nz, stream, tm, stage);
+        return launch_gemm_split(g, p.nz, stream, tm, stage, f16);
     }
     if (!bf16) {
         GemmArgs g;
@@ -521,6 +583,24 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             cur[1] = xin[1];
         }
 
+        // fp16x3: the running-max words of this micro-batch's activations (one word per tensor that feeds a projection)
+        const bool splitmb = (c.compute == IEFVAD_COMPUTE_BF16X6 || c.compute == IEFVAD_COMPUTE_FP16X3) &&
+                             split_eligible(rows, IEF_D, IEF_D, 1);
+        const bool f16mb = splitmb && c.compute == IEFVAD_COMPUTE_FP16X3;
+        float* am = h->amax_dev ? h->amax_dev + kAmaxActBase * IEF_AMAX_FLOATS : nullptr;
+        auto am_in = [&](int m) { return f16mb ? am + IEF_AMAX_FLOATS * m : nullptr; };
+        auto am_att = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * l + m) : nullptr; };
+        auto am_x = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * l + 2 + m) : nullptr; };
+        auto am_z = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * L + k) : nullptr; };
+        auto am_h = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * L + (K + 1) + k) : nullptr; };
+        if (f16mb) {
+            HIP_TRY(hipMemsetAsync(am, 0, (kAmaxTensors - kAmaxActBase) * IEF_AMAX_FLOATS * sizeof(float), stream));
+            hipEvent_t e = tm.begin(ST_CAST);
+            hipLaunchKernelGGL(iefvad_amax_kernel, dim3(2048, 2), dim3(256), 0, stream, cur[0], cur[1], am_in(0), am_in(1), R * D);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+        }
+
         // 1. temporal encoder (imf_vad.py:113-123): L x { in_proj, attention, out_proj + residual, LayerNorm }
         for (int l = 0; l < L; ++l) {
             Proj p;
@@ -530,10 +610,11 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             p.alpha = qscale * 1.4426950408889634f;
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l]; p.Ws[m] = h->in_ws[m][l];
+                p.Wh[m] = h->in_wh[m][l]; p.amaxW[m] = h->in_wa[m][l]; p.amaxA[m] = l == 0 ? am_in(m) : am_x(l - 1, m);
                 p.bias[m] = h->in_b[m][l];
                 if (bf) p.Cb[m] = qkvb[m]; else p.C[m] = qkv[m];
             }
-            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_QKV)) return rc;
+            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
 
             hipEvent_t e = tm.begin(ST_ATT);
             if (bf) {
@@ -548,7 +629,8 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
                 aa.nchunks = nb;
                 // bf16x6: the split attention kernel goes with the split projections (same batch-size rule), so a small
                 // batch is computed exactly as in the f32 mode
-                if (c.compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, IEF_D, IEF_D, 1))
+                for (int m = 0; m < 2; ++m) aa.amax[m] = am_att(l, m);
+                if (splitmb)
                     hipLaunchKernelGGL(iefvad_attention_split_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
                 else
                     hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
@@ -560,9 +642,10 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = att[m]; p.A16[m] = attb[m]; p.W32[m] = h->out_w[m][l]; p.W16[m] = h->out_wb[m][l]; p.Ws[m] = h->out_ws[m][l];
+                p.Wh[m] = h->out_wh[m][l]; p.amaxW[m] = h->out_wa[m][l]; p.amaxA[m] = am_att(l, m);
                 p.bias[m] = h->out_b[m][l]; p.C[m] = ybuf[m]; p.R[m] = cur[m];
             }
-            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_OUT)) return rc;
+            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_OUT)) return rc;
 
             LnArgs la;
             memset(&la, 0, sizeof(la));
@@ -574,6 +657,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
                 // projection, the fp32 tensor is only the next layer's residual (not needed after the last layer)
                 la.y[m] = (!bf || l < L - 1) ? xbuf[m] : nullptr;
                 la.yb[m] = bf ? xb[m] : nullptr;
+                la.amax[m] = am_x(l, m);
             }
             e = tm.begin(ST_LN);
             hipLaunchKernelGGL(iefvad_layernorm_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES, 2), dim3(256), 0, stream, la);
@@ -590,9 +674,10 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = xbuf[m]; p.A16[m] = xb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
+                p.Wh[m] = h->head_wh[m]; p.amaxW[m] = h->head_wa[m]; p.amaxA[m] = am_x(L - 1, m);
             }
             p.C[0] = mu_i; p.C2[0] = lv_i; p.C[1] = mu_e; p.C2[1] = lv_e;
-            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_HEAD)) return rc;
+            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_HEAD)) return rc;
         }
 
         // 3. precision weights + fusion (imf_vad.py:130-144), fp32 in both modes
@@ -607,6 +692,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             fa.n_i_mean = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
             fa.n_e_mean = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
             fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
+            fa.z_amax = am_z(0);
             hipEvent_t e = tm.begin(ST_FUSION);
             hipLaunchKernelGGL(iefvad_fusion_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
             tm.end(e);
@@ -619,13 +705,15 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
             p.A32[0] = z; p.A16[0] = zb; p.W32[0] = h->ref_w1[k]; p.W16[0] = h->ref_w1b[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k];
+            p.Wh[0] = h->ref_w1h[k]; p.amaxW[0] = h->ref_w1a[k]; p.amaxA[0] = am_z(k); p.amaxC[0] = am_h(k);
             p.C[0] = bf ? nullptr : hbuf; p.Cb[0] = bf ? hb : nullptr;
-            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
             p.A32[0] = hbuf; p.A16[0] = hb; p.W32[0] = h->ref_w2[k]; p.W16[0] = h->ref_w2b[k]; p.Ws[0] = h->ref_w2s[k]; p.bias[0] = h->ref_b2[k];
+            p.Wh[0] = h->ref_w2h[k]; p.amaxW[0] = h->ref_w2a[k]; p.amaxA[0] = am_h(k); p.amaxC[0] = am_z(k + 1);
             p.C[0] = z; p.R[0] = z; p.Cb[0] = (bf && k + 1 < K) ? zb : nullptr;
-            if (int rc = launch_proj(p, c.compute, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
         }
 
         // 5. scorer (imf_vad.py:150)

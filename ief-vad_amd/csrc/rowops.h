@@ -28,6 +28,7 @@ struct LnArgs {
     const float* b2[2];
     int nrows;
     float eps;
+    float* amax[2];          // fp16x3 mode: running max |y| of the output tensor (nullable)
 };
 
 __device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const float* b, int lane, float eps) {
@@ -76,6 +77,14 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) *(bf16x4_t*)(yb + 256 * j) = to_bf16x4(v[j]);
     }
+    if (a.amax[mod]) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
+        amax_publish(a.amax[mod], wave_max(m), lane);
+    }
 }
 
 // ---- Student-t / Gaussian precision weights + normalised inverse-variance fusion
@@ -90,6 +99,7 @@ struct FusionArgs {
     float* n_i_mean; float* n_e_mean;   // [N], nullable: mean over D (test.py:131-136)
     int nrows;
     float factor, eps;
+    float* z_amax;              // fp16x3 mode: running max |z| (nullable)
 };
 
 __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
     const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
     if (row >= a.nrows) return;
     const size_t base = (size_t)row * IEF_D + 4 * lane;
-    float si = 0.f, se = 0.f;
+    float si = 0.f, se = 0.f, zm = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const size_t o = base + 256 * j;
@@ -114,12 +124,14 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
             z[e] = __fadd_rn(__fmul_rn(ni[e], mi[e]), __fmul_rn(ne[e], me[e]));
             si += ni[e];
             se += ne[e];
+            zm = fmaxf(zm, fabsf(z[e]));
         }
         if (a.n_i) *(f32x4*)(a.n_i + o) = ni;
         if (a.n_e) *(f32x4*)(a.n_e + o) = ne;
         *(f32x4*)(a.z + o) = z;
         if (a.zb) *(bf16x4_t*)(a.zb + o) = to_bf16x4(z);
     }
+    if (a.z_amax) amax_publish(a.z_amax, wave_max(zm), lane);
     if (a.n_i_mean || a.n_e_mean) {
         si = wave_sum(si) * (1.0f / IEF_D);
         se = wave_sum(se) * (1.0f / IEF_D);
@@ -166,4 +178,17 @@ __global__ __launch_bounds__(256) void iefvad_cast_kernel(const T* in0, const T*
         if (out) *(f32x4*)(out + o) = v;
         if (ob) *(bf16x4_t*)(ob + o) = to_bf16x4(v);
     }
+}
+
+// ---- running max |x| of two tensors (blockIdx.y): the raw inputs of the first projection in fp16x3 mode
+__global__ __launch_bounds__(256) void iefvad_amax_kernel(const float* in0, const float* in1, float* out0, float* out1, size_t n) {
+    const float* in = blockIdx.y ? in1 : in0;
+    float* out = blockIdx.y ? out1 : out0;
+    float m = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx * 4 < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(in + idx * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[e]));
+    }
+    amax_publish(out, wave_max(m), threadIdx.x & 63);
 }

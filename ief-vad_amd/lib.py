@@ -18,8 +18,8 @@ MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
 IN_F32, IN_F16, IN_BF16 = 0, 1, 2
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X6 = 0, 1, 2
-COMPUTE_CODES = {"f32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x6": COMPUTE_BF16X6}
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X6, COMPUTE_FP16X3 = 0, 1, 2, 3
+COMPUTE_CODES = {"f32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x6": COMPUTE_BF16X6, "fp16x3": COMPUTE_FP16X3}
 
 # every symbol include/iefvad.h declares
 SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_workspace_bytes",

@@ -120,6 +120,9 @@ class MMFMIL(nn.Module):
                  three-term bf16 split of both fp32 operands (csrc/gemm_split.h): fp32-accurate -- held to the same
                  tolerances as "f32" -- at the bf16 matrix-core rate.  Batches too small to fill the chip run on the
                  "f32" kernels, so scores are fp32-accurate but not bit-identical across batch sizes in this mode.
+                   "fp16x3" (opt-in, near-fp32): the "bf16x6" flow with two fp16 terms per operand and three products per
+                 multiply-add (22-bit products, half the MFMAs); operands are scaled by powers of two from running max |.|
+                 words the producing kernels maintain (range-safe).  Per-projection error vs fp64 ~1.8x the fp32 path's.
     """
 
     def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
@@ -140,7 +143,7 @@ class MMFMIL(nn.Module):
         if outputs not in ("full", "scores"):
             raise ValueError("outputs must be 'full' or 'scores'")
         if compute not in _lib.COMPUTE_CODES:
-            raise ValueError("compute must be 'f32', 'bf16' or 'bf16x6'")
+            raise ValueError("compute must be 'f32', 'bf16', 'bf16x6' or 'fp16x3'")
         self.outputs = outputs
         self.micro_batch = micro_batch
         self.compute = compute

@@ -1,0 +1,115 @@
+"""The opt-in near-fp32 mode compute="fp16x3" (csrc/gemm_split.h, F16 path): two fp16 terms per operand, three MFMA
+products, operands scaled by powers of two from running max |.| words that the producing kernels maintain.  It must
+meet the fp32 gates of tests/helpers.py; its error against fp64 may exceed the fp32 MFMA path's by a small factor
+(22-bit products), which is measured and bounded here.  Needs a real MI355X: run with `-m gpu`."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import harness, synth
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+B_SPLIT = 48
+
+
+def make_model(sd, compute, K=10, **kw):
+    args = argparse.Namespace(visual_layers=2, visual_head=8, num_refinement_steps=K, lambda_ref=0.5,
+                              noise_model="StudentT", nu=8)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, 2, 8, 10, 10, "cuda", args, compute=compute, **kw)
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval()
+
+
+def run(model, img, ev):
+    with torch.no_grad():
+        out = model(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_forward_meets_the_fp32_gates():
+    sd = synth.make_state_dict(0)
+    img, ev = synth.make_inputs(7, B_SPLIT)
+    cfg = orc.OracleConfig(num_layers=2, num_refinement_steps=10, nu=8)
+    ti, te = torch.from_numpy(img), torch.from_numpy(ev)
+    ref32 = orc.forward(sd, ti, te, cfg)
+    ref64 = orc.forward(sd, ti, te, cfg, dtype=torch.float64)
+    got = run(make_model(sd, "fp16x3"), img, ev)
+    f32 = run(make_model(sd, "f32"), img, ev)
+    worst = 0.0
+    for k in H.BIG_KEYS + ["logits"]:
+        assert np.isfinite(got[k]).all(), k
+        assert np.abs(got[k] - ref32[k].numpy()).max() <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), k
+        e16, e32 = np.abs(got[k] - ref64[k].numpy()).max(), np.abs(f32[k] - ref64[k].numpy()).max()
+        worst = max(worst, e16 / max(e32, 1e-9))
+        assert e16 <= 4.0 * e32 + 5e-7, (k, e16, e32)            # 22-bit products: a small multiple of the fp32 path's error
+    assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref32["logits"].numpy())).max() <= H.TOL_SIGMOID
+    assert not np.array_equal(got["logits"], f32["logits"])
+    print("fp16x3 / f32 error ratio vs fp64 (worst output):", worst)
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 10.0])
+def test_operand_scaling_keeps_the_range(scale):
+    """Input features x 1e-4 (all below fp16's smallest normal) and x 10 (beyond that the softmax saturates and the forward is
+    ill-conditioned in any arithmetic): LayerNorm removes the input scale only after the first projection and attention;
+    the power-of-two operand scales must keep everything within the gates."""
+    sd = synth.make_state_dict(5)
+    img, ev = synth.make_inputs(13, B_SPLIT)
+    img, ev = (img * scale).astype(np.float32), (ev * scale).astype(np.float32)
+    cfg = orc.OracleConfig(num_layers=2, num_refinement_steps=10, nu=8)
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), cfg)
+    got = run(make_model(sd, "fp16x3"), img, ev)
+    for k in H.BIG_KEYS + ["logits"]:
+        assert np.isfinite(got[k]).all(), k
+        assert np.abs(got[k] - ref[k].numpy()).max() <= 2 * H.TOL_BIG, (k, scale)
+    assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref["logits"].numpy())).max() <= 2 * H.TOL_SIGMOID
+
+
+def test_small_batches_run_on_the_fp32_kernels_and_k5_variant():
+    sd = synth.make_state_dict(1)
+    img, ev = synth.make_inputs(5, 3)
+    a = run(make_model(sd, "fp16x3"), img, ev)
+    b = run(make_model(sd, "f32"), img, ev)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    sd5 = synth.make_state_dict(2, 768, 2, 5)
+    img, ev = synth.make_inputs(9, B_SPLIT)
+    cfg = orc.OracleConfig(num_layers=2, num_refinement_steps=5, nu=8)
+    ref = orc.forward(sd5, torch.from_numpy(img), torch.from_numpy(ev), cfg)
+    got = run(make_model(sd5, "fp16x3", K=5, outputs="scores"), img, ev)
+    assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref["logits"].numpy())).max() <= H.TOL_SIGMOID
+
+
+def test_dataset_scores_and_auc_match_the_oracle():
+    seed = 4
+    lengths = synth.lognormal_lengths(seed, 60, 14000)
+    classes = [synth.UCF_CLASSES[i % len(synth.UCF_CLASSES)] for i in range(len(lengths))]
+    total = int(lengths.sum())
+    gt = synth.make_gt(seed, total)
+    sd = synth.make_state_dict(0)
+
+    def items():
+        for i, (n, c) in enumerate(zip(lengths, classes)):
+            img, ev = synth.make_video(seed, i, int(n))
+            ci, _ = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), (c,), torch.tensor([int(n)])
+
+    model = make_model(sd, "fp16x3", outputs="scores")
+    s_gpu, c_gpu, _, _ = harness.score_loader(model, items(), 256, "cuda:0", "ucfcrime", batch_chunks=64)
+    torch.set_num_threads(harness.host_cpu_share())
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    s_cpu, c_cpu, _, _ = harness.score_loader(oracle, items(), 256, "cpu", "ucfcrime")
+    a, b = np.concatenate(s_gpu), np.concatenate(s_cpu)
+    assert a.shape == b.shape == (total,)
+    assert np.abs(a - b).max() <= H.TOL_SIGMOID
+    r_gpu = harness.evaluate_scores(s_gpu, classes, gt, "ucfcrime", verbose=False)
+    r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "ucfcrime", verbose=False)
+    for k in ("roc", "ap", "ano_auc"):
+        assert abs(r_gpu[k] - r_cpu[k]) <= 1e-5, (k, r_gpu[k], r_cpu[k])
