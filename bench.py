@@ -97,8 +97,8 @@ def cpu_baseline(sd, seconds):
 
 
 def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
-    """The same workload on this rank's GPU in another compute mode (no gather), reported beside the headline: the
-    projections on the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32) instead of the six-bf16-product split."""
+    """The same workload on this rank's GPU in another compute mode (no gather), reported beside the headline: "f32" = the
+    projections on the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32); "fp16x3" = the opt-in two-term fp16 split."""
     import iefvad_amd
     model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
                               micro_batch=a.micro_batch, compute=compute)
@@ -118,10 +118,18 @@ def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
     B = img.shape[0]
     gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / steps
     alg = GEMM_FLOPS_PER_SNIPPET * B * T / (gemm_ms * 1e-3) / 1e12
+    if compute == "fp16x3":
+        roof = {"bound": "mfma", "kernel": "iefvad_gemm_split_f16_n128_kernel", "achieved": 3.0 * alg,
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * alg / PEAK_BF16_MFMA_TFLOPS,
+                "algorithmic_fp32_tflops": alg,
+                "note": "opt-in near-fp32 arithmetic: 2-term fp16 split of both scaled fp32 operands, three fp16 MFMA products "
+                        "(2^-21 per product), fp32 accumulation; meets the f32 parity gates (tests/test_gpu_fp16x3.py), error vs "
+                        "fp64 in profiles/r01_mode_accuracy.json"}
+    else:
+        roof = {"bound": "mfma", "kernel": "iefvad_gemm_f32_t256_kernel", "achieved": alg,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_F32_MFMA_TFLOPS}
     return {"compute": compute, "value": B * T * steps / dt, "unit": "snippets/s per GPU", "steps": steps,
-            "ms_per_step": dt / steps * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "iefvad_gemm_f32_t256_kernel", "achieved": alg,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_F32_MFMA_TFLOPS},
+            "ms_per_step": dt / steps * 1e3, "roofline": roof,
             "stage_ms_per_step": {k: v / steps for k, v in stage.items() if k.endswith("_ms")}}
 
 
@@ -241,6 +249,7 @@ def main():
         }
         if world == 1 and a.compute == "bf16x6" and not a.no_extra_modes:   # N=1 only: rank 0 must not linger at N>1
             line["f32_mfma_mode"] = extra_mode(sd, margs, dev, img, ev, a, "f32")
+            line["fp16x3_mode"] = extra_mode(sd, margs, dev, img, ev, a, "fp16x3")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), flush=True)
