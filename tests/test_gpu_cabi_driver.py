@@ -16,8 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_torch_free_c_driver_matches_python_path(tmp_path):
-    L, K, B = 2, 3, 2
+@pytest.mark.parametrize("B,compute", [(2, "f32"), (48, "bf16x6"), (48, "fp16x3")])
+def test_torch_free_c_driver_matches_python_path(tmp_path, B, compute):
+    """B = 2 runs the fp32 kernels; B = 48 is large enough for the split kernels of the bf16x6 / fp16x3 arithmetic."""
+    L, K = 2, 3
     exe = tmp_path / "abi_driver"
     libdir = os.path.dirname(iefvad_amd.lib.LIB_PATH)
     # plain g++: the driver is host-only C++ (HIP runtime API + the C header), no device code, no torch
@@ -35,13 +37,14 @@ def test_torch_free_c_driver_matches_python_path(tmp_path):
         f.write(img.tobytes())
         f.write(ev.tobytes())
     out = tmp_path / "logits.bin"
-    r = subprocess.run([str(exe), str(blob), str(B), str(L), str(K), str(out)], capture_output=True, text=True)
+    r = subprocess.run([str(exe), str(blob), str(B), str(L), str(K), str(out), str(iefvad_amd.lib.COMPUTE_CODES[compute])],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_driver OK" in r.stdout
     got = np.fromfile(out, dtype=np.float32).reshape(B, 256)
     args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5,
                               noise_model="StudentT", nu=8)
-    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, outputs="scores")
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, outputs="scores", compute=compute)
     m.load_state_dict(sd)
     m = m.to("cuda:0").eval()
     with torch.no_grad():
