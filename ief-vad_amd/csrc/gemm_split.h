@@ -85,12 +85,15 @@ struct Split4 {
         }
     }
     // experiment: the same with fp16 terms (round to nearest even)
+    // (one v_cvt_pk_f16_f32 per pair; the remainder is taken from the PACKED value -- v_cvt_f32_f16 on either half --
+    // so that nothing is converted twice: 8 VALU per pair for the two planes)
     __device__ __forceinline__ void plane_f16(unsigned& d0, unsigned& d1, bool peel) {
-        const f16x2 a = {(_Float16)r[0], (_Float16)r[1]}, b = {(_Float16)r[2], (_Float16)r[3]};
+        const f16x2 a = __builtin_convertvector(f32x2{r[0], r[1]}, f16x2), b = __builtin_convertvector(f32x2{r[2], r[3]}, f16x2);
         d0 = __builtin_bit_cast(unsigned, a);
         d1 = __builtin_bit_cast(unsigned, b);
         if (peel) {
-            r[0] -= (float)a[0]; r[1] -= (float)a[1]; r[2] -= (float)b[0]; r[3] -= (float)b[1];
+            const f32x2 fa = __builtin_convertvector(a, f32x2), fb = __builtin_convertvector(b, f32x2);
+            r[0] -= fa[0]; r[1] -= fa[1]; r[2] -= fb[0]; r[3] -= fb[1];
         }
     }
 };
@@ -221,7 +224,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     // half `hf` (k = 8q + 4 (hf & 1) .. + 3) of row-tile (hf >> 1) of the NEXT k-tile: fp32 fragment -> three planes
     auto split_half = [&](int hf, const f32x4& v) {
         Split4 sp;
-        if constexpr (F16) sp.r = v * ascale; else sp.r = v;
+        if constexpr (F16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp.r[e] = v[e] * ascale;       // scalar multiplies: v_pk_mul_f32 is slow beside MFMAs
+        } else {
+            sp.r = v;
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             unsigned d0, d1;
@@ -296,7 +304,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
 #define GS_NAREAD(B) ((B) < 7 ? GS_NSPLIT((B) + 1) : 0)                                      /* fp32 A reads for step B+1 */
 #define GS_NREAD(B) (((B) < 7 ? NP : 0) + GS_NAREAD(B))
 #define GS_NDMA(B) (NA == 4 ? ((B) < 4 ? (F16 ? 3 : 4) : 0) : (F16 ? ((B) < 4 ? 2 : 0) : ((B) < 5 ? 2 : 0)))
-#define GS_NVALU(B) ((B) == 7 ? 4 * NP * NA : GS_EXP_NOSPLIT ? 0 : (F16 ? 24 : 22) * GS_NSPLIT(B))
+#define GS_NVALU(B) ((B) == 7 ? 4 * NP * NA : GS_EXP_NOSPLIT ? 0 : (F16 ? 12 : 22) * GS_NSPLIT(B))
 #define GS_VSLOT(B, g) (((g) + 1) * GS_NVALU(B) / NM - (g) * GS_NVALU(B) / NM)
 #define GS_SLOT(B, g)                                                                                           \
         if ((g) < NM) {                                                                                         \
