@@ -22,6 +22,7 @@ struct AttnArgs {
     __bf16* outb[2];       // the same as bf16 when non-null (A operand of a bf16 out_proj)
     int nchunks;           // chunks per modality in this launch
     float* amax[2];        // fp16x3 mode (attention_split.h only): running max |out| per modality, nullable
+    const float* amax_in[2];   // fp16x3 attention: running max |q k v| of the input tensor (operand scale)
 };
 
 #define ATT_LDK 100

@@ -19,6 +19,9 @@
 // the three-term split) the A fragments of k-step s2 of P V, in the permuted key order 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
 // that the transposed V read reproduces (attention_bf16.h).  Q is split once into registers (72 VGPRs).
 // Per 64-key tile and wave: 72 MFMAs of 32 cycles against 96 of 64 cycles in the fp32 kernel.
+// F16 = true (compute = fp16x3): two fp16 terms per operand and three products (gemm_split.h, F16): q, k, v are scaled by
+// s = 2^(13 - floor(log2 max|qkv|)) (running max from the in_proj epilogue), the scores by s^-2 before the softmax, P by
+// 2^13 and the output by 2^-13 / s.  Two planes per tile: 52 KB of LDS.
 #pragma once
 #include "attention_f32.h"
 #include "gemm_split.h"
@@ -30,32 +33,49 @@
 #define ATS_BUF (3 * ATS_KPLANE)                       // bf16 elements per tile buffer (the K layout is the larger)
 #define ATS_LDS_BYTES (2 * ATS_BUF * 2)                // 79,872 B
 
-// eight fp32 -> three bf16x8 planes (exact three-term split)
-__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+// eight fp32 -> three bf16x8 planes (exact three-term split) / two fp16x8 planes of the scaled values
+template <bool F16, int NP>
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[NP], float scale) {
     Split4 a, b;
-    a.r = lo;
-    b.r = hi;
+    if constexpr (F16) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+        for (int e = 0; e < 4; ++e) { a.r[e] = lo[e] * scale; b.r[e] = hi[e] * scale; }
+    } else {
+        a.r = lo;
+        b.r = hi;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
         unsigned d0, d1, d2, d3;
-        a.plane(d0, d1, p < 2);
-        b.plane(d2, d3, p < 2);
+        if constexpr (F16) { a.plane_f16(d0, d1, p < NP - 1); b.plane_f16(d2, d3, p < NP - 1); }
+        else { a.plane(d0, d1, p < NP - 1); b.plane(d2, d3, p < NP - 1); }
         pl[p] = u32x4{d0, d1, d2, d3};
     }
 }
 
-#define ATS_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
-// c += x * y from the planes of x (A operand) and y (B operand), smallest terms first
-#define ATS_SIX(xp, yp, c)  \
-    ATS_MFMA(xp[2], yp[0], c); ATS_MFMA(xp[0], yp[2], c); ATS_MFMA(xp[1], yp[1], c); \
+#define ATS_MFMA(a, b, c)                                                                                                      \
+    if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); \
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+// c += x * y from the planes of x (A operand) and y (B operand), smallest terms first (six bf16 / three fp16 products)
+#define ATS_SIX(xp, yp, c)                                                                   \
+    if constexpr (!F16) { ATS_MFMA(xp[NP - 1], yp[0], c); ATS_MFMA(xp[0], yp[NP - 1], c); ATS_MFMA(xp[1], yp[1], c); } \
     ATS_MFMA(xp[1], yp[0], c); ATS_MFMA(xp[0], yp[1], c); ATS_MFMA(xp[0], yp[0], c)
 
-__global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs args) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+template <bool F16>
+__device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs) {
+    constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
     const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
     float* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    float qs = 1.0f, s_inv2 = 1.0f, o_inv = 1.0f;      // fp16x3: operand scale of q / k / v, score and output rescale
+    constexpr float kPScale = 8192.0f;                 // P <= 1 -> 2^13
+    if constexpr (F16) {
+        const int e = 13 - amax_exponent(amax_read(args.amax_in[mod]));
+        qs = __builtin_ldexpf(1.0f, e);
+        s_inv2 = __builtin_ldexpf(1.0f, -2 * e);
+        o_inv = __builtin_ldexpf(1.0f, -13 - e);
+    }
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -76,23 +96,25 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
 #define ATS_WRITE(ti, buf)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
         Split4 sp;                                                                                            \
-        sp.r = stg[j];                                                                                        \
+        if constexpr (F16) { _Pragma("unroll") for (int e = 0; e < 4; ++e) sp.r[e] = stg[j][e] * qs; }        \
+        else sp.r = stg[j];                                                                                   \
         const int rowlen = (ti) < 4 ? ATS_KROW : ATS_VROW, plane = (ti) < 4 ? ATS_KPLANE : ATS_VPLANE;        \
         bf16_t* dst = kvs + (buf) * ATS_BUF + (srow0 + 32 * (j & 1)) * rowlen + sch0 * 4 + 32 * (j >> 1);     \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                       \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                      \
             unsigned d0, d1;                                                                                  \
-            sp.plane(d0, d1, p < 2);                                                                          \
+            if constexpr (F16) sp.plane_f16(d0, d1, p < NP - 1); else sp.plane(d0, d1, p < NP - 1);           \
             *(uint2*)(dst + p * plane) = make_uint2(d0, d1);                                                  \
         }                                                                                                     \
     }
 
     ATS_LOAD(0)
     // Q planes (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
-    u32x4 qp[6][3];
+    u32x4 qp[6][NP];
     {
         const float* qptr = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) split8(*(const f32x4*)(qptr + 16 * s), *(const f32x4*)(qptr + 16 * s + 4), qp[s]);
+        for (int s = 0; s < 6; ++s)
+            split8<F16, NP>(*(const f32x4*)(qptr + 16 * s), *(const f32x4*)(qptr + 16 * s + 4), qp[s], qs);
     }
     ATS_WRITE(0, 0)
     __syncthreads();
@@ -124,14 +146,15 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
                 const bf16_t* kp = T + (u * 32 + i) * ATS_KROW + 8 * h;
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
-                    u32x4 ka[3];
+                    u32x4 ka[NP];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) ka[p] = *(const u32x4*)(kp + p * ATS_KPLANE + 16 * s);
+                    for (int p = 0; p < NP; ++p) ka[p] = *(const u32x4*)(kp + p * ATS_KPLANE + 16 * s);
                     ATS_SIX(ka, qp[s], st[2 * ti + u]);
                 }
             }
             if (ti == 3) {
                 // softmax over the 256 keys of query q0 + i: 128 values in this lane, 128 in lane i + 32
+                // (fp16x3: the accumulators hold s^2 x the scores; exp2((st - mx) s^-2) in one fma)
                 float mx = st[0][0];
 #pragma unroll
                 for (int kt = 0; kt < 8; ++kt)
@@ -143,12 +166,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);   // scores arrive in log2 units
+                        const float p = __builtin_amdgcn_exp2f(F16 ? (st[kt][r] - mx) * s_inv2 : st[kt][r] - mx);   // log2 units
                         st[kt][r] = p;
                         sum += p;
                     }
                 sum += __shfl_xor(sum, 32, 64);
-                const float inv = 1.0f / sum;
+                const float inv = (F16 ? kPScale : 1.0f) / sum;      // fp16x3: P is carried as 2^13 P
 #pragma unroll
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -161,15 +184,15 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const f32x16& pr = st[2 * (ti - 4) + u];
-                    u32x4 pp[3];
-                    split8(f32x4{pr[8 * s2], pr[8 * s2 + 1], pr[8 * s2 + 2], pr[8 * s2 + 3]},
-                           f32x4{pr[8 * s2 + 4], pr[8 * s2 + 5], pr[8 * s2 + 6], pr[8 * s2 + 7]}, pp);
+                    u32x4 pp[NP];
+                    split8<F16, NP>(f32x4{pr[8 * s2], pr[8 * s2 + 1], pr[8 * s2 + 2], pr[8 * s2 + 3]},
+                                    f32x4{pr[8 * s2 + 4], pr[8 * s2 + 5], pr[8 * s2 + 6], pr[8 * s2 + 7]}, pp, 1.0f);
                     const bf16_t* vp = T + (u * 32 + 16 * s2) * ATS_VROW + tr_off;
 #pragma unroll
                     for (int dt = 0; dt < 3; ++dt) {
-                        u32x4 vb[3];
+                        u32x4 vb[NP];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
+                        for (int p = 0; p < NP; ++p) {
                             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                                 (__attribute__((address_space(3))) bf16x4*)(vp + p * ATS_VPLANE + dt * 32));
                             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -195,10 +218,24 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
-            om = fmaxf(om, fabsf(o[dt][r]));
+            const float ov = F16 ? o[dt][r] * o_inv : o[dt][r];
+            out[(size_t)qrow * IEF_D + dt * 32 + i] = ov;
+            if constexpr (F16) om = fmaxf(om, fabsf(ov));
         }
-    if (args.amax[mod]) amax_publish(args.amax[mod], wave_max(om), lane);
+    if constexpr (F16) {      // running max |out| for the out_proj operand scale
+        if (args.amax[mod]) amax_publish(args.amax[mod], wave_max(om), lane);
+    }
 }
 #undef ATS_SIX
 #undef ATS_MFMA
+
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs args) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<false>(args, kvs);
+}
+
+// fp16x3
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_f16_kernel(AttnArgs args) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<true>(args, kvs);
+}

@@ -148,6 +148,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_split_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ATS_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_split_f16_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GS_LDS_BYTES_OF(2));
     if (e == hipSuccess && cfg->compute == IEFVAD_COMPUTE_FP16X3) e = hipMalloc((void**)&h->amax_dev, kAmaxWords * sizeof(float));
@@ -589,10 +592,11 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         const bool f16mb = splitmb && c.compute == IEFVAD_COMPUTE_FP16X3;
         float* am = h->amax_dev ? h->amax_dev + kAmaxActBase * IEF_AMAX_FLOATS : nullptr;
         auto am_in = [&](int m) { return f16mb ? am + IEF_AMAX_FLOATS * m : nullptr; };
-        auto am_att = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * l + m) : nullptr; };
-        auto am_x = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * l + 2 + m) : nullptr; };
-        auto am_z = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * L + k) : nullptr; };
-        auto am_h = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 4 * L + (K + 1) + k) : nullptr; };
+        auto am_att = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + m) : nullptr; };
+        auto am_x = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + 2 + m) : nullptr; };
+        auto am_qkv = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + 4 + m) : nullptr; };
+        auto am_z = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * L + k) : nullptr; };
+        auto am_h = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * L + (K + 1) + k) : nullptr; };
         if (f16mb) {
             HIP_TRY(hipMemsetAsync(am, 0, (kAmaxTensors - kAmaxActBase) * IEF_AMAX_FLOATS * sizeof(float), stream));
             hipEvent_t e = tm.begin(ST_CAST);
@@ -611,6 +615,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             for (int m = 0; m < 2; ++m) {
                 p.A32[m] = cur[m]; p.A16[m] = xb[m]; p.W32[m] = h->in_w[m][l]; p.W16[m] = h->in_wb[m][l]; p.Ws[m] = h->in_ws[m][l];
                 p.Wh[m] = h->in_wh[m][l]; p.amaxW[m] = h->in_wa[m][l]; p.amaxA[m] = l == 0 ? am_in(m) : am_x(l - 1, m);
+                p.amaxC[m] = am_qkv(l, m);
                 p.bias[m] = h->in_b[m][l];
                 if (bf) p.Cb[m] = qkvb[m]; else p.C[m] = qkv[m];
             }
@@ -629,8 +634,10 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
                 aa.nchunks = nb;
                 // bf16x6: the split attention kernel goes with the split projections (same batch-size rule), so a small
                 // batch is computed exactly as in the f32 mode
-                for (int m = 0; m < 2; ++m) aa.amax[m] = am_att(l, m);
-                if (splitmb)
+                for (int m = 0; m < 2; ++m) { aa.amax[m] = am_att(l, m); aa.amax_in[m] = am_qkv(l, m); }
+                if (f16mb)
+                    hipLaunchKernelGGL(iefvad_attention_split_f16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
+                else if (splitmb)
                     hipLaunchKernelGGL(iefvad_attention_split_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
                 else
                     hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);

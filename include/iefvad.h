@@ -49,7 +49,7 @@ enum { IEFVAD_IN_F32 = 0, IEFVAD_IN_F16 = 1, IEFVAD_IN_BF16 = 2 };
  *   FP16X3 = opt-in, near-fp32: the BF16X6 data flow with two fp16 terms per operand and three products per
  *            multiply-add (22-bit products, half the MFMAs).  Operands are scaled by powers of two from running
  *            max |.| words that the producing kernels maintain, so the result is range-safe; error against fp64 is
- *            ~1.8x the fp32 MFMA path's (rms) per projection.  Attention stays BF16X6. */
+ *            ~1.8x the fp32 MFMA path's (rms) per projection, below it end to end. */
 enum { IEFVAD_COMPUTE_F32 = 0, IEFVAD_COMPUTE_BF16 = 1, IEFVAD_COMPUTE_BF16X6 = 2, IEFVAD_COMPUTE_FP16X3 = 3 };
 
 typedef struct iefvad_handle iefvad_handle;
