@@ -26,15 +26,18 @@
 //   k-tile t+1 are read and split (11 VALU per element pair: v_cvt_pk_bf16_f32, shift / mask, exact subtractions) while
 //   the MFMAs of k-tile t run.  The A ring therefore runs one tile ahead of the W ring.
 //   W planes are split once, at iefvad_set_weights (iefvad_split_planes_kernel).
-//   LDS reads per wave and tile: 8 KB (A) + 24 KB (W) for 3072 MFMA cycles (the plain bf16 kernel: 12 KB per 512).
-// With one wave per SIMD nothing hides a stall of the wave's in-order instruction stream, so the issue ORDER is pinned
-// with sched_group_barrier: every non-MFMA instruction of a step (split VALU, LDS reads, LDS-DMA) sits between two
+//   LDS reads per wave and tile (NA = 4): 8 KB (A) + 24 KB (W) for 3072 MFMA cycles (the plain bf16 kernel: 12 KB per 512).
+// With one or two waves per SIMD little hides a stall of a wave's in-order instruction stream, so the issue ORDER is
+// pinned with sched_group_barrier: every non-MFMA instruction of a step (split VALU, LDS reads, LDS-DMA) sits between two
 // MFMAs -- an MFMA leaves 8 of its 16 issue cycles free (MI355X_MICROARCH.md, vector-instruction issue cost).
 // Swizzles (ds_read_b128 is served in the 16-lane groups of MI355X_MICROARCH.md, LDS): A image, 16-byte chunk index
 // XOR ((row>>1)&5): lane (r, q) reads chunks 2q, 2q+1 of row r, conflict-free; W image as in gemm_bf16.h (G[(row>>2)&3]).
-// Measured (tools/gemm_tune_split, M = 65,536): 200-207 TFLOP/s fp32-equivalent (1.2 PFLOP/s of bf16 MFMA) vs 137-141 for
-// the fp32 MFMA kernel; main loop 4150-4400 cycles per k-tile at 2.07-2.25 GHz (the chip trades clock for issue density),
-// prologue 5.5 k and epilogue 11.7 k cycles per block (all CUs store at once: one workgroup per CU).
+// Measured (tools/gemm_tune_split, M = 65,536, bias + fp32 store): NA = 2 218-225 TFLOP/s fp32-equivalent (1.3 PFLOP/s of
+// bf16 MFMA), NA = 4 201-209, the fp32 MFMA kernel 137-141.  In-kernel stamps: NA = 2 main loop 3324 cycles per k-tile
+// and wave against 3072 of pure MFMA for a SIMD's two waves, at 1.70 GHz; NA = 4 4150-4400 cycles against 3072 at
+// 2.07-2.25 GHz (the chip trades clock for MFMA density: the kernel is MFMA-power-bound, all-zero operands run 24 % faster),
+// prologue 5.5 k and epilogue 11.7 k cycles per block (all CUs store at once with one workgroup per CU).
+// The F16 instantiation of the same body (two fp16 terms, three products, scaled operands) is the opt-in fp16x3 mode.
 #pragma once
 #include "gemm_bf16.h"
 
