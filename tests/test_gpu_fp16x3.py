@@ -113,3 +113,21 @@ def test_dataset_scores_and_auc_match_the_oracle():
     r_cpu = harness.evaluate_scores(s_cpu, classes, gt, "ucfcrime", verbose=False)
     for k in ("roc", "ap", "ano_auc"):
         assert abs(r_gpu[k] - r_cpu[k]) <= 1e-5, (k, r_gpu[k], r_cpu[k])
+
+
+@pytest.mark.parametrize("compute", ["bf16x6", "fp16x3"])
+@pytest.mark.parametrize("L,K,noise", [(1, 0, "Gaussian"), (3, 2, "StudentT")])
+def test_layer_and_step_counts_at_split_batch_size(compute, L, K, noise):
+    """Other encoder depths / refinement counts at a batch large enough for the split kernels (the running-max slots of the
+    fp16x3 flow are indexed by layer and step): all eight outputs against the oracle within the fp32 gates."""
+    sd = synth.make_state_dict(11, 768, L, K)
+    img, ev = synth.make_inputs(17, B_SPLIT)
+    cfg = orc.OracleConfig(num_layers=L, num_refinement_steps=K, nu=8, noise_model=noise)
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), cfg)
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5, noise_model=noise, nu=8)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, compute=compute)
+    m.load_state_dict(sd)
+    got = run(m.to("cuda:0").eval(), img, ev)
+    for k in H.BIG_KEYS + ["logits"]:
+        assert np.isfinite(got[k]).all(), k
+        assert np.abs(got[k] - ref[k].numpy()).max() <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), (k, compute, L, K)
