@@ -219,8 +219,11 @@ def main():
                  "bf16x6": "f32 emulated: exact 3-term bf16 split of both fp32 operands, 6 bf16 MFMA products, fp32 accumulate",
                  "fp16x3": "near-f32 (22-bit products): 2-term fp16 split of both scaled fp32 operands, 3 fp16 MFMA products, "
                            "fp32 accumulate"}[a.compute]
-        if os.path.exists(tpath) and (a.micro_batch in (0, 256)) and B >= 256:
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+        mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if a.compute == "f32" else 1024)   # library defaults
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("rows_per_launch") == min(B, mb_eff) * T:      # the PMC passes ran at this launch size
+                traffic = tj["traffic_bytes_per_launch"]
         line = {
             "metric": "snippets/sec at [B,T=256,d=768]", "value": value, "unit": "snippets/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -26,7 +26,7 @@ ln_f, ln_w = pick(f, "iefvad_layernorm_kernel"), pick(w, "iefvad_layernorm_kerne
 ln_bytes = 2 * rows * 768 * 4                                  # both modalities, one fp32 tensor in, one out
 fetch_scale = round(ln_bytes / (ln_f[0] * 1024))               # 2 on gfx950
 kf, kw = pick(f, kname), pick(w, kname)
-res = {"source": source, "kernel": kname, "launches_measured": kf[1],
+res = {"source": source, "kernel": kname, "launches_measured": kf[1], "rows_per_launch": rows,
        "FETCH_SIZE_KB_mean": kf[0], "WRITE_SIZE_KB_mean": kw[0],
        "calibration": f"iefvad_layernorm_kernel streams {ln_bytes} B in and out: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
                       f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}",
