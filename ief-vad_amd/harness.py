@@ -211,20 +211,25 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     forward of up to `batch_chunks` chunks; legal because chunks are independent batch rows
     (imf_vad.py:115 attends within a chunk), and the trailing all-zero chunk of a len % 256 == 0 video,
     whose rows the reference slices away (test.py:121), is not computed when `skip_empty_chunks`."""
-    scores: List[np.ndarray] = []
-    wi_means: List[np.ndarray] = []
-    we_means: List[np.ndarray] = []
     classes: List[str] = []
     pend: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
     pend_chunks = 0
+    # results stay on the model's device until the loop is over: the reference synchronises three times per video
+    # (`.cpu()` of prob / w_i / w_e, test.py:119-151); here the forwards are enqueued back to back and the scores of
+    # all videos come back in ONE device-to-host copy at the end
+    dev_prob: List[torch.Tensor] = []
+    dev_wi: List[torch.Tensor] = []
+    dev_we: List[torch.Tensor] = []
+    spans: List[Tuple[int, int]] = []          # (offset into the concatenated device vectors, valid length) per video
+    total = 0
 
     def flush():
-        nonlocal pend, pend_chunks
+        nonlocal pend, pend_chunks, total
         if not pend:
             return
         dt = torch.float32 if len({p[0].dtype for p in pend}) > 1 else pend[0][0].dtype
-        img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device)
-        ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device)
+        img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
+        ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
         out = model(img, ev, None, None, None)
         logits = out['logits'].reshape(-1)
         if 'w_i_mean' in out:
@@ -232,14 +237,14 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         else:
             wi = out['w_i'].reshape(-1, out['w_i'].shape[-1]).mean(dim=-1)     # test.py:131-136
             we = out['w_e'].reshape(-1, out['w_e'].shape[-1]).mean(dim=-1)
-        prob = torch.sigmoid(logits).float().cpu().numpy()
-        wi, we = wi.float().cpu().numpy(), we.float().cpu().numpy()
-        off = 0
+        dev_prob.append(torch.sigmoid(logits).float())
+        dev_wi.append(wi.float())
+        dev_we.append(we.float())
+        off = total
         for ci, _, n in pend:
-            scores.append(prob[off:off + n].copy())          # logits1[0:len_cur] -> sigmoid, test.py:119-121
-            wi_means.append(wi[off:off + n].copy())
-            we_means.append(we[off:off + n].copy())
+            spans.append((off, n))                           # logits1[0:len_cur] -> sigmoid, test.py:119-121
             off += ci.shape[0] * maxlen
+        total = off
         pend, pend_chunks = [], 0
 
     with torch.no_grad():
@@ -253,6 +258,15 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             if batch_chunks <= 0 or pend_chunks >= batch_chunks:
                 flush()
         flush()
+        if dev_prob:
+            prob = torch.cat(dev_prob).cpu().numpy()
+            wi = torch.cat(dev_wi).cpu().numpy()
+            we = torch.cat(dev_we).cpu().numpy()
+        else:
+            prob = wi = we = np.zeros(0, np.float32)
+    scores = [prob[o:o + n].copy() for o, n in spans]
+    wi_means = [wi[o:o + n].copy() for o, n in spans]
+    we_means = [we[o:o + n].copy() for o, n in spans]
     return scores, classes, wi_means, we_means
 
 
