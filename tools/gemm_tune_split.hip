@@ -154,11 +154,13 @@ int main(int argc, char** argv) {
         GemmBArgs g; memset(&g, 0, sizeof(g));
         g.M = M; g.N = 768; g.K = K; g.lda = K; g.ldc = 768; g.epi = EPI_BIAS; g.wplane = 768 * K * 2;
         g.p[0].A = (const bf16_t*)A; g.p[0].W = Wp; g.p[0].bias = bias; g.p[0].C = C; g.p[0].C2 = (float*)dclk; g.p[1] = g.p[0];
-      for (int cfgi = 0; cfgi < 2; ++cfgi) {
+      for (int cfgi = 0; cfgi < 3; ++cfgi) {
         dim3 grid((M / GS_BM) * (768 / (cfgi ? 128 : GS_BN)), 1, 1);
-        printf("%s\n", cfgi ? "128 x 128, two workgroups per CU:" : "128 x 256, one workgroup per CU:");
+        printf("%s\n", cfgi == 2 ? "fp16x3, 128 x 128, two workgroups per CU:" : cfgi ? "128 x 128, two workgroups per CU:" : "128 x 256, one workgroup per CU:");
+        GemmBArgs g2 = gh; g2.epi = EPI_BIAS; g2.p[0].C = C; g2.p[0].C2 = (float*)dclk; g2.p[1] = g2.p[0];
         for (int it = 0; it < 4000; ++it) {
-            if (cfgi) hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), 0, g);
+            if (cfgi == 2) hipLaunchKernelGGL(iefvad_gemm_split_f16_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), 0, g2);
+            else if (cfgi) hipLaunchKernelGGL(iefvad_gemm_split_n128_kernel, grid, dim3(256), GS_LDS_BYTES_OF(2), 0, g);
             else hipLaunchKernelGGL(iefvad_gemm_split_kernel, grid, dim3(256), GS_LDS_BYTES, 0, g);
         }
         CK(hipDeviceSynchronize());
