@@ -80,8 +80,9 @@ def test_small_batches_run_on_the_fp32_kernels_and_k5_variant():
         assert np.array_equal(a[k], b[k]), k
     sd5 = synth.make_state_dict(2, 768, 2, 5)
     img, ev = synth.make_inputs(9, B_SPLIT)
+    img, ev = img.astype(np.float16), ev.astype(np.float16)          # fp16 feature files: cast kernel, then the running max
     cfg = orc.OracleConfig(num_layers=2, num_refinement_steps=5, nu=8)
-    ref = orc.forward(sd5, torch.from_numpy(img), torch.from_numpy(ev), cfg)
+    ref = orc.forward(sd5, torch.from_numpy(img).float(), torch.from_numpy(ev).float(), cfg)
     got = run(make_model(sd5, "fp16x3", K=5, outputs="scores"), img, ev)
     assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref["logits"].numpy())).max() <= H.TOL_SIGMOID
 
