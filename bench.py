@@ -13,8 +13,8 @@ blocks (videos shard embarrassingly), so scaling is weak and `valu
 aggregate.  Weights are seeded synthetic tensors of the reference architecture (K=10, nu=8, StudentT).
 
 Arithmetic (--compute): the default, bf16x6, is fp32-ACCURATE: every fp32 operand of a dense projection is split
-exactly into three bf16 terms and the product is accumulated in fp32 from six bf16 MFMA products (error <= 2^-26
-relative per product, below fp32's own rounding; csrc/gemm_split.h).  It is held to the same parity gates as the fp32
+exactly into three bf16 terms and the product is accumulated in fp32 from six bf16 MFMA products (truncation <= 2^-23 of a product in
+the worst case, ~2^-27 typically -- below the fp32 accumulation rounding that follows; csrc/gemm_split.h).  It is held to the same parity gates as the fp32
 MFMA mode (tests/test_gpu_bf16x6.py) and its error against an fp64 evaluation is not larger.  MI355X multiplies bf16
 16x faster than fp32, so this beats the fp32 MFMA instruction; the same workload on that instruction
 (--compute f32) is timed in the same run and reported as `f32_mfma_mode`.
@@ -123,7 +123,7 @@ def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * alg / PEAK_BF16_MFMA_TFLOPS,
                 "algorithmic_fp32_tflops": alg,
                 "note": "opt-in near-fp32 arithmetic: 2-term fp16 split of both scaled fp32 operands, three fp16 MFMA products "
-                        "(2^-21 per product), fp32 accumulation; meets the f32 parity gates (tests/test_gpu_fp16x3.py), error vs "
+                        "(products to ~2^-20.4 worst case, 2^-23 typical), fp32 accumulation; meets the f32 parity gates (tests/test_gpu_fp16x3.py), error vs "
                         "fp64 in profiles/r01_mode_accuracy.json"}
     else:
         roof = {"bound": "mfma", "kernel": "iefvad_gemm_f32_t256_kernel", "achieved": alg,

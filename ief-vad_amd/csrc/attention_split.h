@@ -4,8 +4,8 @@
 // per (chunk, head) softmax(Q K^T / sqrt(96)) V over ALL 256 keys, q pre-scaled by log2(e)/sqrt(96) in the in_proj
 // epilogue, fp32 q | k | v in, fp32 out.  Both contractions are computed as in gemm_split.h: each fp32 operand is the
 // exact sum of three bf16 terms (round-to-nearest of the running remainder) and a product is accumulated in fp32 from
-// the six bf16 MFMA products of relative size >= 2^-18 (k3 q1 + k1 q3 + k2 q2 + k2 q1 + k1 q2 + k1 q1, and the same for
-// P V); the dropped terms are <= 2^-26 of the product.  Softmax is fp32 on the accumulators, as in the fp32 kernel.
+// the six largest bf16 MFMA products (k3 q1 + k1 q3 + k2 q2 + k2 q1 + k1 q2 + k1 q1, and the same for P V); the dropped
+// terms are <= 2^-23 of the product in the worst case, ~2^-27 typically (gemm_split.h).  Softmax is fp32 on the accumulators, as in the fp32 kernel.
 //
 // One workgroup = (head, chunk, modality, query half): 4 waves x 32 queries, two workgroups per CU (78 KB LDS).
 // K then V stream through a double-buffered 64-key tile.  The STAGING threads split the tile: global fp32 loads of tile

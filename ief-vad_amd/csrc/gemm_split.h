@@ -6,11 +6,14 @@
 // sum of bf16 products than as one v_mfma_f32_32x32x2_f32.  Every fp32 value is the exact sum of three bf16 values
 // obtained by round-to-nearest of the running remainder,
 //       x = x1 + x2 + x3,   x1 = bf16(x),  x2 = bf16(x - x1),  x3 = bf16(x - x1 - x2)
-// (8 + 9 + 9 significant bits >= 24; the subtractions are exact in fp32), and a bf16 x bf16 product is exact in the
-// fp32 accumulator.  Of the nine partial products the kernel keeps the six of relative size >= 2^-18,
+// (|x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|, and what is left after x3 has at most 8 significant bits: it IS x3; the
+// subtractions are exact in fp32), and a bf16 x bf16 product is exact in the fp32 accumulator.  Of the nine partial
+// products the kernel keeps the six of relative size up to 2^-16,
 //       a3 w1 + a1 w3 + a2 w2 + a2 w1 + a1 w2 + a1 w1          (accumulated in that order, smallest first),
-// and drops a2 w3 + a3 w2 + a3 w3 <= 2^-26 |a w|: a quarter of the half-ulp an fp32 multiply itself rounds away.  What
-// is left is fp32 accumulation error, the same kind the fp32 MFMA path (and the reference's CPU GEMM) has; the parity
+// and drops a2 w3 + a3 w2 + a3 w3 <= 2^-23 |a w| in the worst case (both remainders at their half-ulp bound), ~2^-27 |a w|
+// typically -- against the up to 2^-24 of the RUNNING SUM that every fp32 accumulation step rounds away.  What dominates
+// is fp32 accumulation error, the same kind the fp32 MFMA path (and the reference's CPU GEMM) has; measured against
+// fp64 the split kernel's error is below the fp32 MFMA kernel's (tools/gemm_tune_split, tests/test_gpu_bf16x6.py); the parity
 // tests hold this mode to the SAME gates as the fp32 mode (tests/helpers.py TOL_*).  Non-finite inputs differ:
 // inf - inf in the remainder turns an inf operand into NaN (the fp32 path would propagate inf).
 //
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
 
 // F16 = false: three bf16 terms per operand, six products (the production arithmetic).
 // F16 = true (compute = fp16x3, opt-in): two fp16 terms per operand (22 bits), three products h1 g1 + h1 g2 + h2 g1 --
-// half the MFMAs, 2^-21 per product.  fp16 has a 5-bit exponent, so both operands are scaled by powers of two (exact):
+// half the MFMAs; products good to ~2^-20.4 |a w| worst case (2^-23 typical).  fp16 has a 5-bit exponent, so both operands are scaled by powers of two (exact):
 // A by 2^(13 - floor(log2 amaxA)) from the running max |A| word its producer kernel maintained (P.amaxA), W at
 // iefvad_set_weights by the same rule (P.amaxW); the epilogue multiplies the accumulators by the inverse (cscale).
 // Scaled maxima sit in [2^13, 2^14); elements more than 2^27 below their tensor's maximum fall into fp16's subnormals

@@ -43,7 +43,7 @@ enum { IEFVAD_IN_F32 = 0, IEFVAD_IN_F16 = 1, IEFVAD_IN_BF16 = 2 };
  *   BF16   = operands rounded to bf16, fp32 accumulation and fp32 fusion state (throughput mode);
  *   BF16X6 = fp32 operands, each split exactly into three bf16 terms and multiplied as six bf16 MFMA
  *            products with fp32 accumulation: fp32-accurate (held to the F32 mode's tolerances, product
- *            error <= 2^-26 relative) at the bf16 matrix-core rate; everything else is the F32 path.
+ *            error <= 2^-23 relative worst case, ~2^-27 typical) at the bf16 matrix-core rate; everything else is the F32 path.
  *            Small batches (grids that would not fill the chip) use the F32 kernels, so results are
  *            fp32-accurate but not bit-identical across batch sizes in this mode.
  *   FP16X3 = opt-in, near-fp32: the BF16X6 data flow with two fp16 terms per operand and three products per
