@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- snippets/sec of the IEF-VAD fusion-inference forward on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                         # N = 1
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (MMFMIL.forward through libiefvad.so, scores-only outputs) over
-one batch of synthetic [B, T=256, d=768] fp32 image + event feature blocks that are already resident
-in HBM, followed -- when N > 1 -- by the single RCCL all-gather of per-snippet scores.  Default batch:
-BASELINE.json config 4's B = 8192 chunks (2,097,152 snippets) PER GPU; every rank holds its own
-blocks (videos shard embarrassingly), so scaling is weak and `value` is the whole-job
-aggregate.  Weights are seeded synthetic tensors of the reference architecture (K=10, nu=8, StudentT).
+`python bench.py --gpus N` from a plain shell works for N > 1 as well: before anything touches a GPU the process starts
+`python -m torch.distributed.run` with N ranks as a CHILD, relays its output and exits with its code.
+
+A "step" is one pass of the hot path (MMFMIL.forward through libiefvad.so, scores-only outputs) over one batch of
+synthetic [B, T=256, d=768] fp32 image + event feature blocks that are already resident in HBM, followed -- when
+N > 1 -- by the single RCCL all-gather of per-snippet scores (`iefvad_gather_scores`, librccl over xGMI).
+Workload: BASELINE.json config 4, B = 8192 chunks (2,097,152 snippets) IN TOTAL; rank r holds and scores chunks
+[r*B/N, (r+1)*B/N), so scaling is "strong" and `value` is the whole-job rate.  `--scaling weak` keeps
+8192 chunks per GPU instead; a default N > 1 run also measures that variant and reports it as `weak_scaling`.
+Weights are seeded synthetic tensors of the reference architecture (K=10, nu=8, StudentT).
 
 Arithmetic (--compute): the default, bf16x6, is fp32-ACCURATE: every fp32 operand of a dense projection is split
-exactly into three bf16 terms and the product is accumulated in fp32 from six bf16 MFMA products (truncation <= 2^-23 of a product in
-the worst case, ~2^-27 typically -- below the fp32 accumulation rounding that follows; csrc/gemm_split.h).  It is held to the same parity gates as the fp32
-MFMA mode (tests/test_gpu_bf16x6.py) and its error against an fp64 evaluation is not larger.  MI355X multiplies bf16
-16x faster than fp32, so this beats the fp32 MFMA instruction; the same workload on that instruction
-(--compute f32) is timed in the same run and reported as `f32_mfma_mode`.
+exactly into three bf16 terms and the product is accumulated in fp32 from six bf16 MFMA products (csrc/gemm_split.h);
+it is held to the fp32 parity gates (tests/test_gpu_bf16x6.py).  The same workload is timed in the same run in the
+other arithmetic modes and reported as `f32_mfma_mode` (fp32 MFMA instruction), `bf16_mode` (BASELINE configs 3 / 5:
+bf16-rounded operands, fp32 accumulation and state) and `fp16x3_mode`.
 
 The JSON line also carries
-  roofline      the dense-projection GEMM kernel (~85 % of device time): the MFMA FLOPs the kernel executes in a
-                step (bf16x6: six bf16 multiply-adds per algorithmic fp32 multiply-add; the algorithmic rate is
-                `algorithmic_fp32_tflops`) / the sum of that kernel's launch durations in the step, timed with
-                hipEvents on the launch stream inside the timed region, against the dense MFMA peak of the
-                operand type from MI355X_MICROARCH.md (bf16 2500, fp32 157.3 TFLOP/s);
-  cpu_baseline  the CPU oracle (oracle/iefvad_oracle.py, torch CPU ops on all host cores) timed on a
-                bounded sample of the same workload, rank 0 at N=1 only.  A reported baseline, not the target.
+  roofline      the dense-projection GEMM kernel (~85 % of device time).  `achieved` = ALGORITHMIC FLOPs (SURVEY.md 8d:
+                47,185,920 per snippet at K=10) of the rows one launch processes / that kernel's average launch
+                duration, timed with hipEvents on the launch stream inside the timed region; `peak` = dense MFMA peak of
+                the pipe the kernel runs on (MI355X_MICROARCH.md: bf16 2500, fp32 157.3 TFLOP/s).  For the emulated
+                modes `mfma_pipe_util` is the EXECUTED-product rate / peak (6 bf16 products per algorithmic one).
+  cpu_baseline  the CPU oracle (oracle/iefvad_oracle.py, torch CPU ops on the host cores) on a bounded sample of the
+                same workload, rank 0 at N=1 only.  A reported baseline, not the target.
+  ucf_eval      BASELINE config 2 (UCF-Crime-sized synthetic set, 290 videos, ~69.5 k snippets) through harness.test:
+                the reference's per-video call pattern and the cross-video batched pattern, snippets/s wall clock
+                including H2D, |dAUC| against the CPU oracle on a bounded sample, and the oracle's own rate.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,21 +47,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 T, D, H, L, K_STEPS = 256, 768, 8, 2, 10
-GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D) + K_STEPS * 2 * (2 * D * D)
+GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D) + K_STEPS * 2 * (2 * D * D)   # 47,185,920
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
-PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 MFMA (same table)
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
+GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_kernel",
+               "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
+PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
+DTYPE = {"f32": "f32", "bf16": "bf16",
+         "bf16x6": "f32 emulated: exact 3-term bf16 split of both fp32 operands, 6 bf16 MFMA products, fp32 accumulate",
+         "fp16x3": "near-f32 (22-bit products): 2-term fp16 split of both scaled fp32 operands, 3 fp16 MFMA products, "
+                   "fp32 accumulate"}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--chunks", type=int, default=8192, help="chunks [256,768] per GPU per step")
+    p.add_argument("--chunks", type=int, default=8192,
+                   help="chunks [256,768] per step: in total (strong scaling, the default) or per GPU (--scaling weak)")
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     p.add_argument("--micro-batch", type=int, default=0, help="chunks per internal pass (0 = library default)")
     p.add_argument("--outputs", default="scores", choices=["scores", "full"])
     p.add_argument("--compute", default="bf16x6", choices=["f32", "bf16", "bf16x6", "fp16x3"],
@@ -63,9 +79,33 @@ def parse():
                    help="nccl (= RCCL over xGMI) for real multi-GPU runs; gloo only to rehearse N>1 on a one-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-modes", action="store_true",
-                   help="skip the short fp32-MFMA pass that a default (bf16x6) run appends as `f32_mfma_mode`")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
-    return p.parse_args()
+                   help="skip the side passes (f32_mfma_mode, bf16_mode, fp16x3_mode, weak_scaling)")
+    p.add_argument("--no-ucf-eval", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-oracle sample")
+    p.add_argument("--plumbing-only", action="store_true",
+                   help="launcher self-test for machines without a GPU (tests/test_bench_launcher_cpu.py): NO forward runs; "
+                        "every rank fabricates the scores of its shard as a ramp of global snippet indices on the CPU and the "
+                        "launch -> shard -> gather (gloo) -> max-over-ranks -> JSON path is exercised; `value` is null")
+    return p.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 from a plain shell: become the parent of a torch.distributed.run job (no GPU call has happened yet)
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(a) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                                 # rank 0's JSON line (and nothing else) arrives here
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def host_cpu_share():
@@ -77,6 +117,7 @@ def cpu_baseline(sd, seconds):
     """The oracle (CPU restatement of the reference forward) on the host cores: B=8 chunks per call, the
     best-case batched pattern of SURVEY.md 8d, repeated for ~`seconds`."""
     import numpy as np
+    import torch
     from iefvad_amd import synth
     from oracle import iefvad_oracle as orc
     torch.set_num_threads(host_cpu_share())
@@ -96,17 +137,60 @@ def cpu_baseline(sd, seconds):
             "sample": f"oracle forward, B=8 chunks (2048 snippets) per call, median of {len(times)} calls, fp32"}
 
 
-def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
-    """The same workload on this rank's GPU in another compute mode (no gather), reported beside the headline: "f32" = the
-    projections on the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32); "fp16x3" = the opt-in two-term fp16 split."""
+def make_model(sd, margs, dev, a, compute, outputs=None):
     import iefvad_amd
-    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
+    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=outputs or a.outputs,
                               micro_batch=a.micro_batch, compute=compute)
     model.load_state_dict(sd)
-    model = model.to(dev).eval()
+    return model.to(dev).eval()
+
+
+def roofline_block(compute, stage, steps, rows_per_step):
+    """algorithmic GEMM FLOPs of the rows a launch processes / the kernel's average launch duration,
+    against the dense peak of the matrix pipe the kernel issues on."""
+    gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / steps
+    launches = stage["gemm_launches"] / steps
+    flops = GEMM_FLOPS_PER_SNIPPET * rows_per_step                     # algorithmic, per step, this rank
+    achieved = flops / (gemm_ms * 1e-3) / 1e12
+    peak = PEAK_F32_MFMA_TFLOPS if compute == "f32" else PEAK_BF16_MFMA_TFLOPS
+    r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+         "traffic": None, "kernel": GEMM_KERNEL[compute],
+         "pipe": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if compute == "f32" else
+                 ("fp16 MFMA" if compute == "fp16x3" else "bf16 MFMA (v_mfma_f32_16x16x32_bf16)"),
+         "launches_per_step": launches, "avg_launch_ms": gemm_ms / launches,
+         "algorithmic_flops_per_launch": flops / launches,
+         "definition": "achieved = algorithmic GEMM FLOPs (SURVEY 8d, 47,185,920 per snippet) / sum of the kernel's "
+                       "launch durations (hipEvents on the launch stream, inside the timed region)"}
+    ppm = PRODUCTS_PER_MAC[compute]
+    if ppm > 1:
+        r["mfma_pipe_util"] = achieved * ppm / peak
+        r["executed_products_per_algorithmic_mac"] = ppm
+        r["achieved_vs_fp32_mfma_peak"] = achieved / PEAK_F32_MFMA_TFLOPS
+        r["note"] = (f"fp32-accurate emulation: every algorithmic multiply-add is {int(ppm)} MFMA products, so frac cannot "
+                     f"exceed {1 / ppm:.3f}; mfma_pipe_util counts the executed products")
+    return r
+
+
+def traffic_from_profiles(compute, rows_per_launch):
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/), when they ran at this launch size."""
+    for rnd in ("r02", "r01"):
+        name = {"f32": f"{rnd}_gemm_hbm_traffic.json", "bf16x6": f"{rnd}_gemm_split_hbm_traffic.json",
+                "bf16": f"{rnd}_gemm_bf16_hbm_traffic.json"}.get(compute)
+        path = os.path.join(ROOT, "profiles", name) if name else None
+        if path and os.path.exists(path):
+            tj = json.load(open(path))
+            if tj.get("rows_per_launch") == rows_per_launch:
+                return tj["traffic_bytes_per_launch"]
+    return None
+
+
+def run_mode(model, img, ev, steps, warmup=1):
+    """`steps` timed forwards of this rank's blocks (no gather); returns (seconds, summed stage times)."""
+    import torch
     stage = {}
     with torch.no_grad():
-        model(img, ev, None, None, None)
+        for _ in range(warmup):
+            model(img, ev, None, None, None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -115,148 +199,286 @@ def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
                 stage[k] = stage.get(k, 0.0) + v
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    return dt, stage
+
+
+def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
+    """The same workload on this rank's GPU in another arithmetic mode, reported beside the headline."""
+    model = make_model(sd, margs, dev, a, compute)
+    dt, stage = run_mode(model, img, ev, steps)
     B = img.shape[0]
-    gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / steps
-    alg = GEMM_FLOPS_PER_SNIPPET * B * T / (gemm_ms * 1e-3) / 1e12
-    if compute == "fp16x3":
-        roof = {"bound": "mfma", "kernel": "iefvad_gemm_split_f16_n128_kernel", "achieved": 3.0 * alg,
-                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * alg / PEAK_BF16_MFMA_TFLOPS,
-                "algorithmic_fp32_tflops": alg,
-                "note": "opt-in near-fp32 arithmetic: 2-term fp16 split of both scaled fp32 operands, three fp16 MFMA products "
-                        "(products to ~2^-20.4 worst case, 2^-23 typical), fp32 accumulation; meets the f32 parity gates (tests/test_gpu_fp16x3.py), error vs "
-                        "fp64 in profiles/r01_mode_accuracy.json"}
-    else:
-        roof = {"bound": "mfma", "kernel": "iefvad_gemm_f32_t256_kernel", "achieved": alg,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_F32_MFMA_TFLOPS}
-    return {"compute": compute, "value": B * T * steps / dt, "unit": "snippets/s per GPU", "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "roofline": roof,
-            "stage_ms_per_step": {k: v / steps for k, v in stage.items() if k.endswith("_ms")}}
+    value = B * T * steps / dt
+    out = {"compute": compute, "dtype": DTYPE[compute], "value": value, "unit": "snippets/s", "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "roofline": roofline_block(compute, stage, steps, B * T),
+           "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / 1e12,
+           "stage_ms_per_step": {k: v / steps for k, v in stage.items() if k.endswith("_ms")}}
+    del model
+    return out
+
+
+def ucf_eval(sd, margs, dev, a):
+    """BASELINE config 2: UCF-Crime-sized synthetic test set through `harness.test` (the counterpart of the reference's
+    test(), test.py:46-212), fp32 arithmetic.  The loader is an in-memory list of DataLoader-shaped items (no file
+    reads; the host-to-device copies of every video ARE inside the clock)."""
+    import numpy as np
+    import torch
+    from iefvad_amd import harness, synth
+    from oracle import iefvad_oracle as orc
+    from sklearn.metrics import roc_auc_score
+    seed, nvid, total_target = 1, 290, 69500
+    lengths = synth.lognormal_lengths(seed, nvid, total_target)
+    abnormal = [c for c in synth.UCF_CLASSES if c != "Normal"]
+    classes = ["Normal" if i % 2 == 0 else abnormal[(i // 2) % 13] for i in range(nvid)]      # 150 / 140 as test.csv
+    total = int(lengths.sum())
+    gt = synth.make_gt(seed, total)
+    items = []
+    for i, n in enumerate(lengths):
+        img, ev = synth.make_video(seed, i, int(n))
+        ci, _ = harness.process_split(img, T)
+        ce, _ = harness.process_split(ev, T)
+        items.append((torch.from_numpy(ci).unsqueeze(0), torch.from_numpy(ce).unsqueeze(0), (classes[i],),
+                      torch.tensor([int(n)])))
+    args = argparse.Namespace(dataset="ucfcrime", visual_length=T)
+    torch.set_num_threads(host_cpu_share())
+    out = {"workload": f"BASELINE config 2: synthetic UCF-Crime-sized test set, {nvid} videos, {total} snippets, fp32 "
+                       f"features held in host memory, K=10 nu=8 StudentT, harness.test end to end (H2D, forward, "
+                       f"sigmoid, ordered scores, sklearn AUC/AP excluded from the clock)",
+           "videos": nvid, "snippets": total}
+
+    def timed_scores(model, batch_chunks):
+        harness.score_loader(model, items[:4], T, dev, "ucfcrime", batch_chunks=batch_chunks)      # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scores, cls, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks)
+        torch.cuda.synchronize()
+        return scores, cls, time.perf_counter() - t0
+
+    results = {}
+    modes = [("f32", (("per_video", 0), ("batched", 256)))]
+    if a.compute != "f32":
+        modes.append((a.compute, (("batched", 256),)))
+    for compute, patterns in modes:
+        model = make_model(sd, margs, dev, a, compute, outputs="scores")
+        for name, bc in patterns:
+            scores, cls, dt = timed_scores(model, bc)
+            res = harness.evaluate_scores(scores, cls, gt, "ucfcrime", verbose=False)
+            key = f"{name}_{compute}"
+            results[key] = scores
+            out[key] = {"snippets_per_s": total / dt, "seconds": dt, "auc": res["roc"], "ap": res["ap"],
+                        "ano_auc": res["ano_auc"],
+                        "pattern": "one forward per video (test.py:76-117)" if bc == 0 else
+                                   f"chunks of consecutive videos packed into forwards of >= {bc} chunks"}
+        del model
+    # CPU oracle in the reference's per-video pattern on a bounded prefix of the same list
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K_STEPS, nu=8))
+    harness.score_loader(oracle, items[:1], T, "cpu", "ucfcrime")
+    t0 = time.perf_counter()
+    cpu_scores, nsub = [], 0
+    for it in items:
+        s, _, _, _ = harness.score_loader(oracle, [it], T, "cpu", "ucfcrime")
+        cpu_scores += s
+        nsub += len(s[0])
+        if time.perf_counter() - t0 > a.cpu_seconds and len(cpu_scores) >= 8:
+            break
+    t_cpu = time.perf_counter() - t0
+    nv = len(cpu_scores)
+    cpu_cat = np.concatenate(cpu_scores)
+    gt_sub = gt[:16 * nsub]
+    auc_cpu = roc_auc_score(gt_sub, np.repeat(cpu_cat, 16))
+    out["cpu_oracle_per_video"] = {"snippets_per_s": nsub / t_cpu, "seconds": t_cpu, "videos": nv, "snippets": nsub,
+                                   "cores": torch.get_num_threads(), "kind": "port", "auc_on_sample": auc_cpu}
+    for key, scores in results.items():
+        gpu_cat = np.concatenate(scores[:nv])
+        out[key]["max_abs_score_diff_vs_oracle_on_sample"] = float(np.abs(gpu_cat - cpu_cat).max())
+        out[key]["abs_auc_diff_vs_oracle_on_sample"] = float(abs(roc_auc_score(gt_sub, np.repeat(gpu_cat, 16)) - auc_cpu))
+        out[key]["x_cpu_oracle"] = out[key]["snippets_per_s"] / out["cpu_oracle_per_video"]["snippets_per_s"]
+    return out
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # stdout carries exactly ONE line, the JSON record: native libraries (gloo, RCCL's NCCL WARN) and anything else that
+    # writes to file descriptor 1 are sent to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    import torch
     import torch.distributed as dist
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % max(ndev, 1)   # rehearsal: ranks share GPUs
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    gpu = not a.plumbing_only
+    backend = a.dist_backend if gpu else "gloo"
+    if gpu:
+        ndev = torch.cuda.device_count()
+        dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)   # gloo rehearsal: ranks share GPUs
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
-        if a.dist_backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # nccl == RCCL on ROCm
         else:
             dist.init_process_group("gloo")
 
-    import iefvad_amd
-    from iefvad_amd import synth
-    from iefvad_amd.harness import gather_scores
+    def sync():
+        if gpu:
+            torch.cuda.synchronize()
+
+    from iefvad_amd import harness, synth
     margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K_STEPS, lambda_ref=0.5,
                                noise_model="StudentT", nu=8)
-    sd = synth.make_state_dict(0, D, L, K_STEPS)
-    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, outputs=a.outputs,
-                              micro_batch=a.micro_batch, compute=a.compute)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
+    sd = synth.make_state_dict(0, D, L, K_STEPS) if gpu else None
+    model = make_model(sd, margs, dev, a, a.compute) if gpu else None
 
-    B = a.chunks
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    img = torch.randn(B, T, D, device=dev, generator=gen) * 0.45
-    ev = torch.randn(B, T, D, device=dev, generator=gen) * 0.45
+    def shard(total_chunks, scaling):
+        """(first chunk, chunk count) of this rank and the per-rank counts."""
+        if scaling == "weak":
+            return rank * total_chunks, total_chunks, [total_chunks] * world
+        cuts = [r * total_chunks // world for r in range(world + 1)]        # SURVEY 8e: [r*B/R, (r+1)*B/R)
+        return cuts[rank], cuts[rank + 1] - cuts[rank], [cuts[r + 1] - cuts[r] for r in range(world)]
 
-    stage = {}
+    def make_blocks(nchunks):
+        if not gpu:
+            return None, None
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        return (torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45,
+                torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45)
 
-    def step():
-        with torch.no_grad():
-            out = model(img, ev, None, None, None, timed=True)
-        for k, v in model.last_stage_times.items():
-            stage[k] = stage.get(k, 0.0) + v
-        scores = out["logits"].reshape(-1)
+    comm = None
+    gather_impl = None
+    if world > 1 and backend == "nccl":
+        try:
+            comm = harness.ScoreComm(dev)
+            gather_impl = "iefvad_gather_scores (libiefvad -> librccl ncclAllGather on the forward's stream)"
+        except Exception as e:      # keep the measurement alive on RCCL through torch.distributed; say so in the line
+            gather_impl = f"torch.distributed all_gather_into_tensor (iefvad_comm_create failed: {e})"
+    elif world > 1:
+        gather_impl = "torch.distributed gloo (scores staged through the host)"
+
+    def timed_run(img, ev, first, counts, steps, warmup):
+        """Contract timing: `warmup` untimed steps, barrier + sync, exactly `steps` steps, sync + barrier, MAX over
+        ranks.  Returns (max seconds, per-rank seconds, stage sums, last gathered scores)."""
+        stage = {}
+        snips = [c * T for c in counts]
+
+        def step():
+            if gpu:
+                with torch.no_grad():
+                    out = model(img, ev, None, None, None, timed=True)
+                for k, v in model.last_stage_times.items():
+                    stage[k] = stage.get(k, 0.0) + v
+                scores = out["logits"].reshape(-1)
+            else:       # --plumbing-only: the global snippet indices of this rank's shard
+                scores = torch.arange(first * T, (first + counts[rank]) * T, dtype=torch.float32)
+            if world > 1:
+                if comm is not None:
+                    scores = comm.gather(scores, snips)
+                elif backend == "nccl":
+                    scores = harness.gather_scores(scores, counts=snips)
+                else:
+                    scores = harness.gather_scores(scores.cpu(), counts=snips)
+            return scores
+
+        for _ in range(warmup):
+            step()
+        stage.clear()
         if world > 1:
-            scores = gather_scores(scores if a.dist_backend == "nccl" else scores.cpu())
-        return scores
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scores = step()
+        sync()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        per_rank = [mine]
+        if world > 1:
+            tdev = dev if backend == "nccl" else "cpu"
+            tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            allr = torch.empty(world, device=tdev, dtype=torch.float64)
+            dist.all_gather_into_tensor(allr, torch.tensor([mine], device=tdev, dtype=torch.float64))
+            per_rank = allr.tolist()
+        assert scores.numel() == sum(snips) and bool(torch.isfinite(scores).all())
+        return dt, per_rank, stage, scores
 
-    for _ in range(a.warmup):
-        step()
-    stage.clear()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        scores = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev if a.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert scores.numel() == world * B * T and bool(torch.isfinite(scores).all())
+    first, B, counts = shard(a.chunks, a.scaling)
+    img, ev = make_blocks(B)
+    dt, per_rank, stage, scores = timed_run(img, ev, first, counts, a.steps, a.warmup)
+    total_chunks = sum(counts)
+    gathered = int(scores.numel())
+    in_order = bool((scores == torch.arange(total_chunks * T, dtype=torch.float32)).all()) if not gpu else None
+
+    weak = None
+    if gpu and world > 1 and a.scaling == "strong" and not a.no_extra_modes:
+        del img, ev, scores
+        wimg, wev = make_blocks(a.chunks)
+        wsteps = max(2, min(a.steps, 3))
+        wdt, wper, _, _ = timed_run(wimg, wev, rank * a.chunks, [a.chunks] * world, wsteps, 1)
+        weak = {"value": world * a.chunks * T * wsteps / wdt, "unit": "snippets/s", "steps": wsteps,
+                "ms_per_step": wdt / wsteps * 1e3, "chunks_per_gpu": a.chunks,
+                "per_rank_ms_per_step": [t / wsteps * 1e3 for t in wper]}
+        del wimg, wev
+        img, ev = make_blocks(B)
 
     if rank == 0:
-        snippets = world * B * T * a.steps
-        value = snippets / dt
-        gemm_ms = (stage["qkv_gemm_ms"] + stage["out_gemm_ms"] + stage["head_gemm_ms"] + stage["refine_gemm_ms"]) / a.steps
-        launches = stage["gemm_launches"] / a.steps
-        gemm_flops = GEMM_FLOPS_PER_SNIPPET * B * T                     # per step, this rank
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-        traffic = None      # HBM-side bytes per GEMM launch from the committed PMC passes (same rows per launch)
-        tpath = os.path.join(ROOT, "profiles", {"f32": "r01_gemm_hbm_traffic.json", "bf16x6": "r01_gemm_split_hbm_traffic.json"}
-                             .get(a.compute, "none"))
-        peak = PEAK_F32_MFMA_TFLOPS if a.compute == "f32" else PEAK_BF16_MFMA_TFLOPS
-        # bf16x6: each algorithmic (fp32) multiply-add is executed as six bf16 MFMA multiply-adds
-        executed = achieved * {"bf16x6": 6.0, "fp16x3": 3.0}.get(a.compute, 1.0)
-        kernel = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_kernel",
-                  "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}[a.compute]
-        dtype = {"f32": "f32", "bf16": "bf16",
-                 "bf16x6": "f32 emulated: exact 3-term bf16 split of both fp32 operands, 6 bf16 MFMA products, fp32 accumulate",
-                 "fp16x3": "near-f32 (22-bit products): 2-term fp16 split of both scaled fp32 operands, 3 fp16 MFMA products, "
-                           "fp32 accumulate"}[a.compute]
-        mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if a.compute == "f32" else 1024)   # library defaults
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("rows_per_launch") == min(B, mb_eff) * T:      # the PMC passes ran at this launch size
-                traffic = tj["traffic_bytes_per_launch"]
+        value = total_chunks * T * a.steps / dt
         line = {
-            "metric": "snippets/sec at [B,T=256,d=768]", "value": value, "unit": "snippets/s",
+            "metric": "snippets/sec at [B,T=256,d=768]", "value": value if gpu else None, "unit": "snippets/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"synthetic [B={B},T=256,d=768] fp32 image+event blocks per GPU resident in HBM "
-                                   f"(BASELINE config 4 batch), K=10 nu=8 StudentT, seeded random weights, "
-                                   f"outputs={a.outputs}, projections={a.compute}",
-                       "chunks_per_gpu": B, "snippets_per_step": world * B * T,
-                       "parallelism": f"video-sharded x{world}, score all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s",
-                         "frac": executed / peak, "traffic": traffic,
-                         "kernel": kernel,
-                         "algorithmic_fp32_tflops": achieved,
-                         "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "launches_per_step": launches,
-                         "avg_launch_ms": gemm_ms / launches,
-                         "flops_per_launch": gemm_flops / launches,
-                         "executed_mfma_flops_per_launch": gemm_flops / launches * {"bf16x6": 6.0, "fp16x3": 3.0}.get(a.compute, 1.0),
-                         "note": ("achieved / peak are the bf16 MFMA FLOPs the kernel executes (six bf16 multiply-adds per "
-                                  "algorithmic fp32 multiply-add of SURVEY 8d) against the dense bf16 MFMA peak; the algorithmic "
-                                  "rate is algorithmic_fp32_tflops = flops_per_launch / avg_launch_ms"
-                                  if a.compute == "bf16x6" else
-                                  "achieved = algorithmic GEMM FLOPs (SURVEY 8d) / kernel time")},
-            "stage_ms_per_step": {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")},
-            "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": DTYPE[a.compute],
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: synthetic [B={total_chunks},T=256,d=768] fp32 image+event blocks "
+                                   f"resident in HBM ({'B in total, rank r holds chunks [r*B/N,(r+1)*B/N)' if a.scaling == 'strong' else 'B per GPU'}), "
+                                   f"K=10 nu=8 StudentT, seeded random weights, outputs={a.outputs}, projections={a.compute}",
+                       "chunks_total": total_chunks, "chunks_per_gpu": counts, "snippets_per_step": total_chunks * T,
+                       "parallelism": (f"video-sharded x{world}, one score all-gather per step" if world > 1 else "single GPU")},
+            "per_rank_ms_per_step": [t / a.steps * 1e3 for t in per_rank],
         }
-        if world == 1 and a.compute == "bf16x6" and not a.no_extra_modes:   # N=1 only: rank 0 must not linger at N>1
-            line["f32_mfma_mode"] = extra_mode(sd, margs, dev, img, ev, a, "f32")
-            line["fp16x3_mode"] = extra_mode(sd, margs, dev, img, ev, a, "fp16x3")
-        if world == 1 and not a.no_cpu_baseline:
+        if gpu:
+            roof = roofline_block(a.compute, stage, a.steps, B * T)
+            mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if a.compute == "f32" else 1024)     # library defaults
+            roof["traffic"] = traffic_from_profiles(a.compute, min(B, mb_eff) * T)
+            line["roofline"] = roof
+            line["stage_ms_per_step"] = {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")}
+            line["end_to_end_tflops_per_gpu"] = TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12
+        else:
+            line["plumbing_only"] = "no forward ran: fabricated scores, launcher / shard / gather / timing self-test"
+            line["gathered_in_order"] = in_order
+        if world > 1:
+            line["rccl_ranks"] = comm.nranks if comm is not None else (dist.get_world_size() if backend == "nccl" else 0)
+            line["dist_backend"] = backend
+            line["gather"] = gather_impl
+            line["gathered_scores"] = gathered
+            if weak is not None:
+                line["weak_scaling"] = weak
+        if gpu and world == 1 and not a.no_extra_modes:     # N=1 only: rank 0 must not linger at N>1
+            for key, mode in (("f32_mfma_mode", "f32"), ("bf16_mode", "bf16"), ("fp16x3_mode", "fp16x3"), ("bf16x6_mode", "bf16x6")):
+                if mode != a.compute:
+                    line[key] = extra_mode(sd, margs, dev, img, ev, a, mode)
+        img = ev = None
+        if gpu and world == 1 and not a.no_ucf_eval:
+            model = None
+            torch.cuda.empty_cache()
+            line["ucf_eval"] = ucf_eval(sd, margs, dev, a)
+        if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

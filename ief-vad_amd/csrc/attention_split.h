@@ -220,7 +220,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float ov = F16 ? o[dt][r] * o_inv : o[dt][r];
             out[(size_t)qrow * IEF_D + dt * 32 + i] = ov;
-            if constexpr (F16) om = fmaxf(om, fabsf(ov));
+            if constexpr (F16) om = amax_fold(om, ov);
         }
     if constexpr (F16) {      // running max |out| for the out_proj operand scale
         if (args.amax[mod]) amax_publish(args.amax[mod], wave_max(om), lane);

@@ -40,6 +40,12 @@ __device__ __forceinline__ float wave_max(float v) {
 #define IEF_AMAX_WAYS 32
 #define IEF_AMAX_STRIDE 32          // floats between the words of one tensor: one 128-byte line each
 #define IEF_AMAX_FLOATS (IEF_AMAX_WAYS * IEF_AMAX_STRIDE)
+// fold |v| into a running maximum, ignoring non-finite values: an inf / NaN element (the reference lets them propagate,
+// test.py:90-95 only replaces NaN) must poison its own chunk, not the power-of-two operand scale of the whole tensor
+__device__ __forceinline__ float amax_fold(float m, float v) {
+    const float a = fabsf(v);
+    return fmaxf(m, a < __builtin_inff() ? a : 0.f);
+}
 __device__ __forceinline__ void amax_publish(float* slot, float wave_amax, int lane) {
     if (lane == 0) {
         float* word = slot + (blockIdx.x % IEF_AMAX_WAYS) * IEF_AMAX_STRIDE;

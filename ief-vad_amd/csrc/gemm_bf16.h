@@ -313,7 +313,7 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
             }
             if (amax_out) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+                for (int e = 0; e < 4; ++e) vmax = amax_fold(vmax, v[e]);
             }
         }
     }

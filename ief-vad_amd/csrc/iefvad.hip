@@ -16,6 +16,7 @@
 #include "attention_bf16.h"
 #include "attention_split.h"
 #include "common.h"
+#include "gather.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
 #include "gemm_split.h"
@@ -90,6 +91,7 @@ struct iefvad_handle {
     _Float16* head_wh[2];                   const float* head_wa[2];
     _Float16* ref_w1h[IEFVAD_MAX_STEPS];    const float* ref_w1a[IEFVAD_MAX_STEPS];
     _Float16* ref_w2h[IEFVAD_MAX_STEPS];    const float* ref_w2a[IEFVAD_MAX_STEPS];
+    struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
 };
 static const int kAmaxTensors = 512, kAmaxActBase = 256;   // tensors with a running max: [0, 256) matrices, [256, 512) activations
 static const int kAmaxWords = kAmaxTensors * IEF_AMAX_FLOATS;
@@ -163,6 +165,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     return 0;
 }
 
+static void release_events(iefvad_handle* h);
+
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
@@ -170,6 +174,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena_s) (void)hipFree(h->arena_s);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
+    release_events(h);
     delete h;
 }
 
@@ -354,9 +359,35 @@ extern "C" size_t iefvad_workspace_bytes(const iefvad_handle* h, int32_t B) {
 // ------------------------------------------------------------------------------------------------
 enum Stage { ST_QKV = 0, ST_ATT, ST_OUT, ST_LN, ST_HEAD, ST_FUSION, ST_REFINE, ST_SCORER, ST_CAST, ST_COUNT };
 
+// hipEvents are pooled on the handle and reused by every timed call (a timed forward of one micro-batch brackets ~35
+// launches; creating and destroying 70 events per call would sit inside bench.py's timed region).
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipError_t err = hipSuccess;
+    hipEvent_t take() {
+        if (used == ev.size()) {
+            hipEvent_t e = nullptr;
+            hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) {
+                if (err == hipSuccess) err = r;
+                return nullptr;
+            }
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void release_all() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        used = 0;
+    }
+};
+
 struct Timer {
     bool on = false;
     hipStream_t stream = nullptr;
+    EventPool* pool = nullptr;
     struct Span { int stage; hipEvent_t a, b; };
     std::vector<Span> spans;
     int gemm_launches = 0;
@@ -364,8 +395,9 @@ struct Timer {
         if (!on) return nullptr;
         Span s;
         s.stage = stage;
-        (void)hipEventCreate(&s.a);
-        (void)hipEventCreate(&s.b);
+        s.a = pool->take();
+        s.b = pool->take();
+        if (!s.a || !s.b) return nullptr;          // pool->err is reported by iefvad_forward_timed
         (void)hipEventRecord(s.a, stream);
         spans.push_back(s);
         return s.b;
@@ -374,6 +406,14 @@ struct Timer {
         if (on && b) (void)hipEventRecord(b, stream);
     }
 };
+
+static void release_events(iefvad_handle* h) {
+    if (h->events) {
+        h->events->release_all();
+        delete h->events;
+        h->events = nullptr;
+    }
+}
 
 static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
     if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
@@ -747,30 +787,33 @@ extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const voi
                                     iefvad_stage_times* times) {
     if (!times) return fail("iefvad_forward_timed: null times");
     hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return fail("iefvad_forward_timed: null handle");
+    if (!h->events) h->events = new (std::nothrow) EventPool();
+    if (!h->events) return fail("iefvad_forward_timed: out of host memory");
+    EventPool& pool = *h->events;
+    pool.used = 0;
+    pool.err = hipSuccess;
     Timer tm;
     tm.on = true;
     tm.stream = stream;
-    hipEvent_t t0, t1;
-    HIP_TRY(hipEventCreate(&t0));
-    HIP_TRY(hipEventCreate(&t1));
+    tm.pool = &pool;
+    hipEvent_t t0 = pool.take(), t1 = pool.take();
+    if (!t0 || !t1) return fail("iefvad_forward_timed: hipEventCreate: %s", hipGetErrorString(pool.err));
     HIP_TRY(hipEventRecord(t0, stream));
     int rc = forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, stream, tm);
     (void)hipEventRecord(t1, stream);
     hipError_t se = hipStreamSynchronize(stream);
+    if (rc) return rc;
+    if (pool.err != hipSuccess) return fail("iefvad_forward_timed: hipEventCreate: %s", hipGetErrorString(pool.err));
+    if (se != hipSuccess) return fail("iefvad_forward_timed: %s", hipGetErrorString(se));
     float acc[ST_COUNT] = {0};
     for (auto& s : tm.spans) {
         float ms = 0.f;
-        if (se == hipSuccess && rc == 0) (void)hipEventElapsedTime(&ms, s.a, s.b);
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
         acc[s.stage] += ms;
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
     }
     float total = 0.f;
-    if (se == hipSuccess && rc == 0) (void)hipEventElapsedTime(&total, t0, t1);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
-    if (rc) return rc;
-    if (se != hipSuccess) return fail("iefvad_forward_timed: %s", hipGetErrorString(se));
+    HIP_TRY(hipEventElapsedTime(&total, t0, t1));
     memset(times, 0, sizeof(*times));
     times->total_ms = total;
     times->qkv_gemm_ms = acc[ST_QKV];
@@ -783,6 +826,115 @@ extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const voi
     times->scorer_ms = acc[ST_SCORER];
     times->cast_ms = acc[ST_CAST];
     times->gemm_launches = tm.gemm_launches;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU score gather (include/iefvad.h; csrc/gather.h binds librccl at run time)
+// ------------------------------------------------------------------------------------------------
+#define RCCL_TRY(api, expr)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int iefvad_comm_unique_id(void* id_bytes) {
+    if (!id_bytes) return fail("iefvad_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == IEFVAD_COMM_ID_BYTES, "ncclUniqueId size");
+    const char* why = "";
+    const RcclApi* api = rccl_api(&why);
+    if (!api) return fail("iefvad_comm_unique_id: %s", why);
+    ncclUniqueId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    memcpy(id_bytes, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int iefvad_comm_create(const void* id_bytes, int32_t nranks, int32_t rank, iefvad_comm** out) {
+    if (!id_bytes || !out) return fail("iefvad_comm_create: null argument");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("iefvad_comm_create: rank %d of %d", rank, nranks);
+    const char* why = "";
+    const RcclApi* api = rccl_api(&why);
+    if (!api) return fail("iefvad_comm_create: %s", why);
+    iefvad_comm* c = new (std::nothrow) iefvad_comm();
+    if (!c) return fail("iefvad_comm_create: out of host memory");
+    memset(c, 0, sizeof(*c));
+    c->rank = rank;
+    hipError_t e = hipGetDevice(&c->device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail("iefvad_comm_create: %s", hipGetErrorString(e));
+    }
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    ncclResult_t r = api->CommInitRank(&c->comm, nranks, id, rank);
+    if (r == ncclSuccess) r = api->CommCount(c->comm, &c->nranks);
+    if (r != ncclSuccess) {
+        if (c->comm) (void)api->CommDestroy(c->comm);
+        delete c;
+        return fail("iefvad_comm_create: %s", api->GetErrorString(r));
+    }
+    if (c->nranks != nranks) {
+        const int got = c->nranks;
+        (void)api->CommDestroy(c->comm);
+        delete c;
+        return fail("iefvad_comm_create: RCCL reports %d ranks, caller said %d", got, nranks);
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int32_t iefvad_comm_nranks(const iefvad_comm* c) { return c ? c->nranks : 0; }
+
+extern "C" void iefvad_comm_destroy(iefvad_comm* c) {
+    if (!c) return;
+    const RcclApi* api = rccl_api(nullptr);
+    if (api && c->comm) (void)api->CommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t count, const int64_t* counts, float* gathered,
+                                    void* stream_) {
+    if (!c || !gathered) return fail("iefvad_gather_scores: null argument");
+    const RcclApi* api = rccl_api(nullptr);
+    if (!api) return fail("iefvad_gather_scores: librccl not bound");
+    hipStream_t stream = (hipStream_t)stream_;
+    bool equal = true;
+    if (counts) {
+        for (int r = 0; r < c->nranks; ++r) {
+            if (counts[r] < 0) return fail("iefvad_gather_scores: counts[%d] = %lld", r, (long long)counts[r]);
+            if (counts[r] != counts[0]) equal = false;
+        }
+        count = (size_t)counts[c->rank];
+    }
+    if (count > 0 && !local) return fail("iefvad_gather_scores: null local buffer");
+    if (equal) {   // the common case (bench, balanced shards): ONE collective
+        if (count == 0) return 0;
+        RCCL_TRY(api, api->AllGather(local, gathered, count, ncclFloat32, c->comm, stream));
+        return 0;
+    }
+    // unequal shards: one grouped point-to-point exchange -- rank r's slice lands at its running offset on every peer
+    size_t off = 0, my_off = 0;
+    RCCL_TRY(api, api->GroupStart());
+    ncclResult_t first_bad = ncclSuccess;
+    for (int r = 0; r < c->nranks; ++r) {
+        const size_t n = (size_t)counts[r];
+        if (r == c->rank) {
+            my_off = off;
+        } else {
+            ncclResult_t a = count ? api->Send(local, count, ncclFloat32, r, c->comm, stream) : ncclSuccess;
+            ncclResult_t b = n ? api->Recv(gathered + off, n, ncclFloat32, r, c->comm, stream) : ncclSuccess;
+            if (first_bad == ncclSuccess) first_bad = (a != ncclSuccess) ? a : b;
+        }
+        off += n;
+    }
+    ncclResult_t ge = api->GroupEnd();      // always close the group, even after a failed enqueue
+    if (first_bad != ncclSuccess) return fail("iefvad_gather_scores: %s", api->GetErrorString(first_bad));
+    if (ge != ncclSuccess) return fail("iefvad_gather_scores: ncclGroupEnd: %s", api->GetErrorString(ge));
+    if (count && gathered + my_off != local)
+        HIP_TRY(hipMemcpyAsync(gathered + my_off, local, count * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 

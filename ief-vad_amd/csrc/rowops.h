@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
+            for (int e = 0; e < 4; ++e) m = amax_fold(m, v[j][e]);
         amax_publish(a.amax[mod], wave_max(m), lane);
     }
 }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
             z[e] = __fadd_rn(__fmul_rn(ni[e], mi[e]), __fmul_rn(ne[e], me[e]));
             si += ni[e];
             se += ne[e];
-            zm = fmaxf(zm, fabsf(z[e]));
+            zm = amax_fold(zm, z[e]);
         }
         if (a.n_i) *(f32x4*)(a.n_i + o) = ni;
         if (a.n_e) *(f32x4*)(a.n_e + o) = ne;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void iefvad_amax_kernel(const float* in0, cons
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx * 4 < n; idx += (size_t)gridDim.x * blockDim.x) {
         const f32x4 v = *(const f32x4*)(in + idx * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[e]));
+        for (int e = 0; e < 4; ++e) m = amax_fold(m, v[e]);
     }
     amax_publish(out, wave_max(m), threadIdx.x & 63);
 }

@@ -227,7 +227,11 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         nonlocal pend, pend_chunks, total
         if not pend:
             return
-        dt = torch.float32 if len({p[0].dtype for p in pend}) > 1 else pend[0][0].dtype
+        # dtype as the files hold it (dataset.py:37-38,49-50); the model widens with `.to(torch.float)` per modality
+        # (imf_vad.py:41-42), so a batch that mixes dtypes -- across videos OR between the two modalities -- is widened
+        # to fp32 here rather than narrowed to the first tensor's type
+        dts = {p[0].dtype for p in pend} | {p[1].dtype for p in pend}
+        dt = torch.float32 if len(dts) > 1 else pend[0][0].dtype
         img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
         ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
         out = model(img, ev, None, None, None)
@@ -301,7 +305,11 @@ class FeatureFilePipeline:
     def _open(self, idx):
         p = self.paths[idx]
         pe = p.replace('rgb', self.event_dir)
-        return (p,) + self._header(p), (pe,) + self._header(pe)
+        hi, he = self._header(p), self._header(pe)
+        if tuple(hi[0]) != tuple(he[0]):
+            # the reference would fail later, at the model's residual add of mismatched lengths; fail at the file
+            raise ValueError(f"{pe}: event features {tuple(he[0])} do not match the image features {tuple(hi[0])} of {p}")
+        return (p,) + hi, (pe,) + he
 
     @staticmethod
     def _fill(dst: np.ndarray, src):
@@ -571,18 +579,96 @@ def partition_by_snippets(lengths: Sequence[int], world: int) -> List[Tuple[int,
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def gather_scores(local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather variable-length fp32 score vectors in rank order (one padded all_gather; counts first).
-    Backend "nccl" is RCCL over xGMI on ROCm; "gloo" serves the CPU tests."""
+class ScoreComm:
+    """The RCCL communicator of the score gather, owned by libiefvad (`iefvad_comm_*`, include/iefvad.h): created
+    once per process over an initialised torch.distributed group, whose store only carries the 128-byte unique id
+    from rank 0 to the other ranks.  The gather itself is `iefvad_gather_scores` on the caller's HIP stream."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import lib as _lib
+        self._lib = _lib.load_library()
+        self._last_error = _lib.last_error
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            if self._lib.iefvad_comm_unique_id(buf) != 0:
+                raise RuntimeError("iefvad_comm_unique_id: " + self._last_error())
+            ident = [bytes(buf.raw)]
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._lib.iefvad_comm_create(C.c_char_p(ident[0]), self.world, self.rank, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("iefvad_comm_create: " + self._last_error())
+        self.nranks = int(self._lib.iefvad_comm_nranks(self._h))      # what RCCL reports
+
+    def gather(self, local: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+        import ctypes as C
+        local = local.reshape(-1).float().contiguous()
+        assert local.is_cuda and local.device == self.device
+        if counts is None:
+            counts = [local.numel()] * self.world
+        assert len(counts) == self.world and counts[self.rank] == local.numel(), (counts, local.numel())
+        out = torch.empty(int(sum(counts)), dtype=torch.float32, device=self.device)
+        carr = (C.c_int64 * self.world)(*[int(c) for c in counts])
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self._lib.iefvad_gather_scores(self._h, C.c_void_p(local.data_ptr()), local.numel(), carr,
+                                                C.c_void_p(out.data_ptr()), st)
+        if rc != 0:
+            raise RuntimeError("iefvad_gather_scores: " + self._last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.iefvad_comm_destroy(self._h)
+            self._h = None
+
+
+_score_comms: Dict[object, ScoreComm] = {}
+
+
+def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Rank-order concatenation of every rank's fp32 score vector, on every rank (= the reference's sequential
+    order, test.py:123-129,153, because shards are contiguous ranges of the test list).
+
+    `counts` are the per-rank lengths.  Every rank can compute them from the shared test list
+    (`partition_by_snippets`), so pass them whenever possible: then nothing but the scores travels and nothing
+    synchronises with the host -- equal counts are ONE all-gather.  Without `counts` the lengths are exchanged first
+    (one small all-gather and a host read).
+    HIP tensors on an "nccl" (= RCCL) group go through the library's own `iefvad_gather_scores`; CPU tensors (the
+    gloo tests) through torch.distributed."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts) if counts else 0
+    local = local.reshape(-1).float()
+    if counts is None:
+        n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+        allc = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(allc, n, group=group)
+        counts = allc.tolist()
+    counts = [int(c) for c in counts]
+    if local.is_cuda and dist.get_backend(group) == "nccl":
+        key = (group, local.device.index)
+        if key not in _score_comms:
+            _score_comms[key] = ScoreComm(local.device, group)
+        return _score_comms[key].gather(local, counts)
+    if len(set(counts)) == 1:
+        out = torch.empty(world * counts[0], dtype=torch.float32, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    mx = max(counts)
     buf = torch.zeros(mx, dtype=torch.float32, device=local.device)
-    buf[:local.numel()] = local.reshape(-1).float()
+    buf[:local.numel()] = local
     out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])
+
+
+def shard_counts(lengths: Sequence[int], world: int) -> List[int]:
+    """Snippets per rank under `partition_by_snippets` -- what every rank passes to `gather_scores(counts=...)`."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    return [int(lengths[a:b].sum()) for a, b in partition_by_snippets(lengths, world)]

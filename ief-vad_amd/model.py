@@ -232,6 +232,21 @@ class MMFMIL(nn.Module):
             raise RuntimeError("iefvad_set_weights: " + _lib.last_error())
         self._weights_sig = sig
 
+    def refresh_weights(self):
+        """Force the library to re-read (and re-pack / re-split) the parameters on the next forward.  The shim notices
+        `load_state_dict`, `.to()`, optimizer steps and any in-place op on a Parameter (they change the storage pointer
+        or the tensor version), but NOT writes made through `param.data` (e.g. `p.data.mul_(0.999)` in an EMA or a
+        clipping utility): those bypass the version counter, so call this after them."""
+        self._weights_sig = None
+
+    def load_state_dict(self, *args, **kw):
+        self._weights_sig = None
+        return super().load_state_dict(*args, **kw)
+
+    def _apply(self, fn, *args, **kw):
+        self._weights_sig = None
+        return super()._apply(fn, *args, **kw)
+
     # ------------------------------------------------------------------ forward
     def _prepare_input(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype not in _IN_DTYPES:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 1
+#define IEFVAD_ABI_VERSION 2
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -163,6 +163,36 @@ int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C,
  * planes[n..2n) = bf16(x - p0), planes[2n..3n) = bf16(x - p0 - p1), round-to-nearest-even; x == p0 + p1 + p2
  * for finite x.  What iefvad_set_weights applies to every projection matrix in IEFVAD_COMPUTE_BF16X6. */
 int iefvad_split_bf16x3(const float* src, void* planes, size_t n, void* stream);
+
+/* ---- multi-GPU score gather ------------------------------------------------------------------
+ * The reference has no collective at all (/root/reference/main.py:7 imports torch.distributed and never uses it);
+ * what it fixes is the ORDER of the score vector: per-video scores are concatenated in test-list order and the
+ * ground truth is indexed by the running snippet offset (/root/reference/test.py:123-129,153).  Videos shard across
+ * ranks in contiguous ranges, so the rank-order concatenation of the ranks' score vectors is that order, and one
+ * RCCL exchange over xGMI closes the evaluation.  librccl.so.1 is bound at run time (dlopen; a copy the process has
+ * already loaded -- PyTorch's -- is preferred), so single-GPU users never load it.
+ *
+ * One process per GPU.  Rank 0 calls iefvad_comm_unique_id and hands the 128 bytes to the other ranks by any
+ * host-side channel (the Python harness uses the torch.distributed store); every rank then calls
+ * iefvad_comm_create with the device it will gather on current.  */
+#define IEFVAD_COMM_ID_BYTES 128
+typedef struct iefvad_comm iefvad_comm;
+
+int iefvad_comm_unique_id(void* id_bytes /* host, IEFVAD_COMM_ID_BYTES */);
+int iefvad_comm_create(const void* id_bytes, int32_t nranks, int32_t rank, iefvad_comm** out);
+/* number of ranks RCCL itself reports for the communicator (ncclCommCount); 0 for a NULL handle */
+int32_t iefvad_comm_nranks(const iefvad_comm* c);
+void iefvad_comm_destroy(iefvad_comm* c);
+
+/* gathered[offset(r) .. offset(r) + counts[r]) = rank r's `local[0 .. counts[r])`, for every r, on every rank;
+ * offset(r) = counts[0] + ... + counts[r-1].  `local`, `gathered` are device pointers to fp32; `counts` is a HOST
+ * array of nranks element counts that every rank passes identically (shards are cut from the shared, ordered test
+ * list -- harness.partition_by_snippets -- so no count exchange is needed), or NULL when every rank contributes
+ * `count` elements.  Equal counts run as ONE ncclAllGather; unequal counts as one grouped ncclSend/ncclRecv
+ * exchange (every pair has a direct xGMI link) plus a device-to-device copy of the rank's own slice.
+ * Enqueued on `stream` (hipStream_t); returns without synchronising. */
+int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t count, const int64_t* counts, float* gathered,
+                         void* stream);
 
 const char* iefvad_last_error(void);
 void iefvad_destroy(iefvad_handle* h);

@@ -63,3 +63,32 @@ def compare_outputs(out, g, tol_big=TOL_BIG, tol_logit=TOL_LOGIT, tol_sig=TOL_SI
         errs[k] = float(np.abs(a - g[k]).max())
         assert errs[k] <= tol_big, (k, errs)
     return errs
+
+
+def write_config1_set(tmp, golden_dir=GOLDEN):
+    """The synthetic config-1 .npy set written to disk exactly as tests/golden/make_golden.py wrote it for
+    the reference's own test() run: 16 videos over the 14 UCF class keys, one NaN element, one fp16 file.
+    Returns (golden capture, args namespace, gt, state_dict)."""
+    import argparse
+    g = np.load(os.path.join(golden_dir, "harness_config1.npz"))
+    seed = int(g["seed"])
+    rows = []
+    for i, (n, c) in enumerate(zip(g["lengths"], g["classes"])):
+        img, ev = synth.make_video(seed, i, int(n))
+        if i == 2:
+            img[5, 7] = np.nan
+        if i == 5:
+            img, ev = img.astype(np.float16), ev.astype(np.float16)
+        d = tmp / "feat" / "rgb" / str(c)
+        d.mkdir(parents=True, exist_ok=True)
+        (tmp / "feat" / "event_thr_10" / str(c)).mkdir(parents=True, exist_ok=True)
+        p = str(d / f"v{i:03d}__5.npy")
+        np.save(p, img)
+        np.save(p.replace("rgb", "event_thr_10"), ev)
+        rows.append((p, str(c)))
+    csv = tmp / "test.csv"
+    csv.write_text("path,label\n" + "".join(f"{p},{c}\n" for p, c in rows))
+    gt = synth.make_gt(seed, int(g["lengths"].sum()))
+    sd = synth.make_state_dict(int(g["wseed"]))
+    args = argparse.Namespace(dataset="ucfcrime", visual_length=256, test_list=str(csv), exp_name="t")
+    return g, args, gt, sd

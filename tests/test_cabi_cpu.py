@@ -46,7 +46,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
 
 def test_create_rejects_bad_config_without_touching_the_gpu(lib):
     h = C.c_void_p()
-    base = dict(abi_version=1, embed_dim=768, seq_len=256, num_heads=8, num_layers=2, num_steps=10,
+    base = dict(abi_version=L.ABI_VERSION, embed_dim=768, seq_len=256, num_heads=8, num_layers=2, num_steps=10,
                 noise_model=1, compute=0, lambda_ref=0.5, nu=8.0, epsilon=1e-8, micro_batch=0)
     for bad, frag in [(dict(embed_dim=512), "D=768"), (dict(num_layers=0), "num_layers"), (dict(num_steps=65), "num_steps"),
                       (dict(noise_model=7), "Unsupported noise_model"), (dict(abi_version=9), "abi_version"),
@@ -56,6 +56,18 @@ def test_create_rejects_bad_config_without_touching_the_gpu(lib):
         assert frag in L.last_error(), (bad, L.last_error())
         assert not h.value
     assert lib.iefvad_workspace_bytes(None, 4) == 0
+
+
+def test_gather_entry_points_reject_bad_arguments_without_a_gpu(lib):
+    """iefvad_comm_* / iefvad_gather_scores validate before they touch RCCL or the device."""
+    h = C.c_void_p()
+    ident = C.create_string_buffer(L.COMM_ID_BYTES)
+    assert lib.iefvad_comm_create(ident, 2, 2, C.byref(h)) != 0 and "rank 2 of 2" in L.last_error()
+    assert lib.iefvad_comm_create(None, 1, 0, C.byref(h)) != 0 and "null" in L.last_error()
+    assert lib.iefvad_comm_unique_id(None) != 0
+    assert lib.iefvad_comm_nranks(None) == 0
+    assert lib.iefvad_gather_scores(None, None, 0, None, None, None) != 0 and "null" in L.last_error()
+    lib.iefvad_comm_destroy(None)
 
 
 def test_shim_refuses_cpu_tensors():

@@ -32,7 +32,7 @@ def run(model, img, ev):
 
 def test_native_library_is_loaded():
     lib = iefvad_amd.lib.load_library()
-    assert lib.iefvad_abi_version() == 1
+    assert lib.iefvad_abi_version() == iefvad_amd.lib.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libiefvad.so" in f.read()
 

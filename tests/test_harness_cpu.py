@@ -9,6 +9,7 @@ import torch
 
 from iefvad_amd import harness, synth
 from oracle import iefvad_oracle as orc
+from tests import helpers as H
 
 
 def test_process_split_matches_reference_rule():
@@ -25,29 +26,7 @@ def test_process_split_matches_reference_rule():
 @pytest.fixture(scope="module")
 def config1(tmp_path_factory, golden_dir):
     """The synthetic config-1 .npy set written to disk exactly as make_golden.py wrote it."""
-    g = np.load(os.path.join(golden_dir, "harness_config1.npz"))
-    tmp = tmp_path_factory.mktemp("cfg1")
-    seed = int(g["seed"])
-    rows = []
-    for i, (n, c) in enumerate(zip(g["lengths"], g["classes"])):
-        img, ev = synth.make_video(seed, i, int(n))
-        if i == 2:
-            img[5, 7] = np.nan
-        if i == 5:
-            img, ev = img.astype(np.float16), ev.astype(np.float16)
-        d = tmp / "feat" / "rgb" / str(c)
-        d.mkdir(parents=True, exist_ok=True)
-        (tmp / "feat" / "event_thr_10" / str(c)).mkdir(parents=True, exist_ok=True)
-        p = str(d / f"v{i:03d}__5.npy")
-        np.save(p, img)
-        np.save(p.replace("rgb", "event_thr_10"), ev)
-        rows.append((p, str(c)))
-    csv = tmp / "test.csv"
-    csv.write_text("path,label\n" + "".join(f"{p},{c}\n" for p, c in rows))
-    gt = synth.make_gt(seed, int(g["lengths"].sum()))
-    sd = synth.make_state_dict(int(g["wseed"]))
-    args = argparse.Namespace(dataset="ucfcrime", visual_length=256, test_list=str(csv), exp_name="t")
-    return g, args, gt, sd
+    return H.write_config1_set(tmp_path_factory.mktemp("cfg1"), golden_dir)
 
 
 def test_loader_items_have_reference_shapes(config1):
@@ -166,3 +145,36 @@ def test_streaming_file_pipeline_matches_per_video_loop(config1):
     by_len = {n: nch for _, n, nch in meta}
     assert by_len[256] == 1 and by_len[257] == 2 and by_len[512] == 2 and by_len[37] == 1 and by_len[1500] == 6
     assert img.shape[0] == sum(nch for _, _, nch in meta)
+
+
+def test_mixed_dtype_between_modalities_is_widened_not_narrowed():
+    """fp16 image features with fp32 event features: the reference casts each modality with `.to(torch.float)`
+    (imf_vad.py:41-42), so the event features must reach the model at full precision (not cast to the image dtype)."""
+    seen = []
+
+    def model(img, ev, *_):
+        seen.append((img.dtype, ev.dtype, ev.clone()))
+        return {"logits": torch.zeros(img.shape[0], img.shape[1], 1), "w_i": torch.zeros_like(img, dtype=torch.float32),
+                "w_e": torch.zeros_like(img, dtype=torch.float32)}
+
+    img, ev = synth.make_video(3, 0, 40)
+    ci, _ = harness.process_split(img.astype(np.float16), 256)
+    ce, _ = harness.process_split(ev, 256)
+    item = (torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([40]))
+    for bc in (0, 4):
+        seen.clear()
+        harness.score_loader(model, [item], 256, "cpu", "ucfcrime", batch_chunks=bc)
+        assert seen[0][0] == seen[0][1] == torch.float32
+        assert torch.equal(seen[0][2][0, :40], torch.from_numpy(ev))          # event features bit-exact, not fp16-rounded
+
+
+def test_pipeline_rejects_event_file_of_another_length(tmp_path):
+    d = tmp_path / "rgb"
+    d.mkdir()
+    (tmp_path / "event_thr_10").mkdir()
+    p = str(d / "a__5.npy")
+    np.save(p, np.zeros((40, 768), np.float32))
+    np.save(p.replace("rgb", "event_thr_10"), np.zeros((41, 768), np.float32))
+    pipe = harness.FeatureFilePipeline([p], ["Normal"], 256, "event_thr_10", "cpu")
+    with pytest.raises(ValueError, match="do not match"):
+        list(pipe.batches())
