@@ -58,9 +58,14 @@ __device__ __forceinline__ float amax_read(const float* slot) {
     return wave_max(lane < IEF_AMAX_WAYS ? slot[lane * IEF_AMAX_STRIDE] : 0.f);
 }
 
-// floor(log2(amax)) for a finite positive amax; 13 (scale 2^0 below) for zero / non-finite
+// floor(log2(amax)) for a finite positive amax; 13 (scale 2^0 below) for zero / non-finite.  Capped at 30: a single huge
+// but finite outlier (|x| > 2^30 -- the reference's fp32 chain overflows to NaN within that element's chunk from ~1e19 on)
+// must not push every other value of the tensor into fp16's subnormals.  With the cap the outlier's own scaled value
+// overflows fp16 instead, which turns ITS chunk into NaN through the attention and leaves the other chunks exact.
+#define IEF_AMAX_EXP_CAP 30
 __device__ __forceinline__ int amax_exponent(float amax) {
     const unsigned b = __float_as_uint(amax);
     const int e = (int)((b >> 23) & 0xff);
-    return (e == 0 || e == 0xff) ? 13 : e - 127;
+    if (e == 0 || e == 0xff) return 13;
+    return e - 127 < IEF_AMAX_EXP_CAP ? e - 127 : IEF_AMAX_EXP_CAP;
 }

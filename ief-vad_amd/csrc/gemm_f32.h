@@ -304,3 +304,109 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_small_kernel(GemmArgs 
 #undef GLDS16
     gemm_epilogue<1, 1>(args, P, acc, res, m0, n0, wr, wc, i, h);
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Lowest-latency variant for the reference's per-video call pattern (B = 1 .. a few chunks, M = 256 B rows): 32 x 32
+// block tile, 4 waves as 2 x 2 of ONE 16 x 16 accumulator on v_mfma_f32_16x16x4_f32.  A launch has 4x the blocks of the
+// 64 x 64 kernel (a 256 x 768 projection: 192 blocks instead of 48 on 256 CUs) and a wave's dependent MFMA chain is
+// 192 x 40 cycles = 3.2 us instead of 384 x 64 = 10.2 us.  k-tiles are 1/3 the MFMA time of the 64 x 64 kernel's, shorter
+// than an L2 round trip, so the LDS ring has 4 slots filled three k-tiles ahead behind a counted s_waitcnt vmcnt.
+//
+// Same summation order per output element as the 32x32x2 kernels -- k = 8s + {0,4,1,5,2,6,3,7}, k-tiles ascending -- so
+// the results are bit-identical to them: MFMA j (j = 0, 1) of the 8-group s takes from lane group q = lane >> 4 the
+// k = 8s + 2j + (q >> 1) + 4 (q & 1), i.e. the instruction's own k order 0..3 is (0,4,1,5) then (2,6,3,7).  A lane reads
+// the 16-byte chunk 2s + (q & 1) of its row (the same image and swizzle as the other kernels; conflict-free for this
+// pattern too: the eight even rows of a 16-lane group land on chunk ^ {0..7}) and picks elements (q >> 1) + 2j.
+// ------------------------------------------------------------------------------------------------------------
+#define GEMT_BM 32
+#define GEMT_BN 32
+#define GEMT_STAGES 4
+#define GEMT_SLOT ((GEMT_BM + GEMT_BN) * GEMM_BK)        // floats per ring slot: 64 rows x 128 B = 8 KB
+
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[GEMT_STAGES * GEMT_SLOT];   // 32 KB
+    const GemmProblem& P = args.p[blockIdx.z];
+    const int ntn = args.N / GEMT_BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * GEMT_BM, n0 = tn * GEMT_BN;
+    const int K = args.K, lda = args.lda;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // staging: one LDS-DMA instruction = 8 rows x 128 B; wave w moves rows 8w..8w+7 of the A tile and of the W tile
+    const int srow = lane >> 3, sch = lane & 7;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * lda), 0,
+                                                       (int)((GEMT_BM - 1) * lda + K) * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * K), 0,
+                                                       (int)((GEMT_BN - 1) * K + K) * 4, 0x00020000);
+    const int grow = uw * 8 + srow;                                  // row inside the 32-row tile
+    const int ssw = (grow >> 1) & 7;
+    const int voA = (grow * lda + ((sch ^ ssw) << 2)) * 4;
+    const int voW = (grow * K + ((sch ^ ssw) << 2)) * 4;
+#define GLDS16(rs, vo, so, lp) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lp), 16, vo, so, 0, 0)
+#define GEMT_STAGE(kt_, slot_)                                                                    \
+    {                                                                                             \
+        float* d = smem + (slot_) * GEMT_SLOT + uw * 8 * GEMM_BK;                                 \
+        GLDS16(rsA, voA, (kt_) * GEMM_BK * 4, d);                                                 \
+        GLDS16(rsW, voW, (kt_) * GEMM_BK * 4, d + GEMT_BM * GEMM_BK);                             \
+    }
+    const int arow = wr * 16 + r16, brow = wc * 16 + r16;
+    const int fsw = (r16 >> 1) & 7;                                  // (row >> 1) & 7 of both fragment rows (16 | 16 wr)
+    const int aoff = arow * GEMM_BK, boff = GEMT_BM * GEMM_BK + brow * GEMM_BK;
+    const bool hi = (q >> 1) != 0;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nk = K / GEMM_BK;
+    // prologue: k-tiles 0, 1, 2 in flight (nk >= 3 for every K the library uses; guarded for smaller K)
+    GEMT_STAGE(0, 0)
+    if (nk > 1) GEMT_STAGE(1, 1)
+    if (nk > 2) GEMT_STAGE(2, 2)
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed: each tile is 2 instructions per wave, issued in order
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tile kt visible to every wave; every wave is done with tile kt - 1
+        if (kt + 3 < nk) GEMT_STAGE(kt + 3, (kt + 3) % GEMT_STAGES)      // slot of tile kt - 1: free since the barrier
+        const float* S = smem + (kt % GEMT_STAGES) * GEMT_SLOT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = ((2 * s + (q & 1)) ^ fsw) << 2;
+            const f32x4 fa = *(const f32x4*)(S + aoff + ch);
+            const f32x4 fb = *(const f32x4*)(S + boff + ch);
+            const float a0 = hi ? fa[1] : fa[0], a1 = hi ? fa[3] : fa[2];
+            const float b0 = hi ? fb[1] : fb[0], b1 = hi ? fb[3] : fb[2];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+        }
+    }
+#undef GEMT_STAGE
+#undef GLDS16
+    // epilogue, accumulator map of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int epi = args.epi, ldc = args.ldc;
+    const float alpha = args.alpha;
+    const int n = n0 + wc * 16 + r16;
+    const float bv = P.bias[n];
+    float* Cb = P.C;
+    int nn = n;
+    float scale = 1.f;
+    if (epi == EPI_HEADS && n >= IEF_D) { Cb = P.C2; nn = n - IEF_D; }
+    if (epi == EPI_QKV && n < args.qcols) scale = alpha;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * 16 + 4 * q + r;
+        const size_t o = (size_t)m * ldc + nn;
+        float v = acc[r] + bv;
+        if (epi == EPI_QKV) v *= scale;
+        else if (epi == EPI_BIAS_RELU) v = (v < 0.f) ? 0.f : v;
+        else if (epi == EPI_BIAS_RESID) v = v + P.R[(size_t)m * ldc + n];
+        else if (epi == EPI_REFINE) v = P.R[(size_t)m * ldc + n] - alpha * v;
+        Cb[o] = v;
+    }
+}

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -415,19 +416,29 @@ static void release_events(iefvad_handle* h) {
     }
 }
 
+// A/B switch for tests and tools (IEFVAD_NO_TINY_GEMM=1): route small problems to the 64x64 kernel as before round 2
+static const bool g_force_no_tiny = [] { const char* v = getenv("IEFVAD_NO_TINY_GEMM"); return v && v[0] == '1'; }();
+
 static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
     if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
         return fail("gemm: shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
                     GEMM_BK);
-    // Three tilings of the same contraction, bit-identical to each other (same k order per output element):
+    // Four tilings of the same contraction, bit-identical to each other (same k order per output element):
     //   128x256 / 3-slot ring (iefvad_gemm_f32_t256_kernel)  the throughput kernel, when its grid fills the chip;
     //   128x128 / double buffer (iefvad_gemm_f32_kernel)      mid-size grids or N not a multiple of 256;
-    //   64x64 (iefvad_gemm_f32_small_kernel)                  small M: 4x the blocks, a quarter of the MFMA chain.
+    //   64x64 (iefvad_gemm_f32_small_kernel)                  small M: 4x the blocks, a quarter of the MFMA chain;
+    //   32x32 on 16x16x4 MFMAs (iefvad_gemm_f32_tiny_kernel)  the per-video pattern (B = 1 .. a few chunks): 16x the
+    //                                                         blocks, a wave's chain is 3.2 us instead of 10 / 41 us.
     const int blocks128 = (a.M / GEMM_BM) * (a.N / GEMM_BN) * nz;
+    const int blocks64 = (a.M / GEMS_BM) * (a.N / GEMS_BN) * nz;
     const bool t256_ok = (a.N % GB2_BN == 0) && (a.K % 16 == 0) && (a.K >= 32);
     const int blocks256 = t256_ok ? (a.M / GB2_BM) * (a.N / GB2_BN) * nz : 0;
+    const bool tiny = blocks64 < 320 && !g_force_no_tiny;      // < 1.25 blocks of 64x64 per CU: the chain, not the chip, bounds it
     hipEvent_t e = tm.begin(stage);
-    if (blocks256 >= 256) {
+    if (tiny) {
+        dim3 grid((a.M / GEMT_BM) * (a.N / GEMT_BN), 1, nz);
+        hipLaunchKernelGGL(iefvad_gemm_f32_tiny_kernel, grid, dim3(256), 0, stream, a);
+    } else if (blocks256 >= 256) {
         GemmBArgs b;
         memset(&b, 0, sizeof(b));
         b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldc = a.ldc; b.epi = a.epi; b.alpha = a.alpha; b.qcols = a.qcols;

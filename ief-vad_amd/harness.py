@@ -5,7 +5,7 @@ multi-GPU sharding.  Counterparts of
   * `test()`                                      /root/reference/test.py:46-212,
                                                    train/ucf_test.py:16-216, train/xd_test.py:15-210
   * `compute_ano_auc`                             /root/reference/test.py:332-348
-  * `run_test` (robustness sweep)                 /root/reference/test2.py:35-123
+  * `run_test` (robustness sweep)                 /root/reference/test2.py:35-123 (`PerturbationSweep`)
 The model is any callable with the reference's `model(img, ev, padding_mask, text, lengths)` contract.
 """
 from __future__ import annotations
@@ -467,94 +467,144 @@ def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, 
 
 
 # ------------------------------------------------------------------------------------------------
-# robustness sweep (second inference caller): /root/reference/test2.py:16-123
+# robustness sweep -- the second inference caller of the forward (/root/reference/test2.py:35-123, levels :29-32)
 # ------------------------------------------------------------------------------------------------
-SWEEP_CFGS = {   # test2.py:29-32
-    "IMG_NOISE": {"sigma_img": [0, 0.05, 0.1, 0.2, 0.3, 0.5], "sigma_ev": [0]},
-    "EV_NOISE": {"sigma_ev": [0, 0.05, 0.1, 0.2, 0.3, 0.5], "sigma_img": [0]},
-}
+SWEEP_LEVELS = (0, 0.05, 0.1, 0.2, 0.3, 0.5)      # fraction of a chunk's time steps that gets attenuated
 
 
-def brier_score(pred, gt):
-    return np.mean((pred - gt) ** 2)
+def sweep_plan():
+    """(name, sigma_img, sigma_ev) for the twelve runs of the reference's sweep: every level on the image features
+    with the event features untouched, then the other way round."""
+    return ([("IMG_NOISE", s, 0) for s in SWEEP_LEVELS] + [("EV_NOISE", 0, s) for s in SWEEP_LEVELS])
 
 
-def kl_divergence(pred_clean, pred_noisy, eps=1e-8):
-    p, q = np.clip(pred_clean, eps, 1 - eps), np.clip(pred_noisy, eps, 1 - eps)
-    return np.mean(p * np.log(p / q) + (1 - p) * np.log((1 - p) / (1 - q)))
+class SweepResult(tuple):
+    """The 12 numbers `run_test` returns (test2.py:119-123), in its order, with names."""
+    FIELDS = ("brier", "kl", "w_img_mean", "w_ev_mean", "auc", "ap", "w_img_anomalous", "w_ev_anomalous",
+              "w_img_normal", "w_ev_normal", "w_img_change", "w_ev_change")
+
+    def __getattr__(self, name):
+        try:
+            return self[self.FIELDS.index(name)]
+        except ValueError:
+            raise AttributeError(name) from None
 
 
-def run_perturbation_test(args, model, loader, gt, device, sigma_img=0, sigma_ev=0, clean_cache: Optional[dict] = None):
-    """Counterpart of `run_test` (test2.py:35-123): per video one clean and one perturbed forward, where
-    the perturbation scales a random `int(T * sigma)` subset of TIME STEPS (dim 1, all chunks alike) of one
-    modality by 0.01 (:71-77; indices from `torch.randperm`, so seeding torch reproduces the reference's
-    draw sequence).  Returns the reference's 12-tuple.  `clean_cache` (a dict kept by the caller across
-    sweep levels) lets the clean forward, identical for every level, run once instead of 12 times."""
-    from sklearn.metrics import average_precision_score, roc_auc_score
+class PerturbationSweep:
+    """Robustness sweep over one test list, organised for the device instead of per video:
+
+      * the videos are unpacked once (shape rule and unconditional `nan_to_num` of test2.py:52-60) and packed across
+        videos into batches of >= `batch_chunks` chunks (chunks are independent batch rows);
+      * the CLEAN pass -- identical for all twelve levels -- runs once; what later levels need from it stays on the
+        device: the clean probabilities, and the per-dimension sums of the clean fusion weights;
+      * a level draws its attenuated time steps with `torch.randperm(T)` once per video and modality, image first, in
+        list order -- the draw sequence of test2.py:71-77, so seeding torch reproduces the reference's subsets -- and
+        scales those rows by 0.01 inside the packed batch (every chunk of the video alike, as `x[:, idx]` does);
+      * Brier score, KL divergence, ROC-AUC / AP (`device_auc_ap`) and the weight statistics are reduced on the device
+        from per-snippet values and the 16-frames-per-snippet ground truth, never materialising the x16 repeat.
+
+    `model` must return the full `w_i` / `w_e` tensors (outputs="full")."""
+
+    def __init__(self, args, model, loader, gt, device, batch_chunks: int = 64, repeat: int = 16):
+        self.model, self.device, self.repeat = model, torch.device(device), repeat
+        self.T = T = args.visual_length
+        self.videos: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
+        for item in loader:
+            img, ev, n = item[0].squeeze(0), item[1].squeeze(0), int(item[3])
+            if n < T:
+                img, ev = img.unsqueeze(0), ev.unsqueeze(0)
+            self.videos.append((torch.nan_to_num(img), torch.nan_to_num(ev), n))
+        self.batches: List[List[int]] = [[]]
+        load = 0
+        for v, (img, _, _) in enumerate(self.videos):
+            self.batches[-1].append(v)
+            load += img.shape[0]
+            if load >= batch_chunks and v + 1 < len(self.videos):
+                self.batches.append([])
+                load = 0
+        self.total = sum(n for _, _, n in self.videos)
+        g = torch.as_tensor(np.asarray(gt)[: repeat * self.total], dtype=torch.float64).reshape(self.total, repeat)
+        self.gt = g.to(self.device)
+        self.pos = self.gt.sum(dim=1)                        # anomalous frames of each snippet
+        self.clean_passes = 0
+        self._clean = None
+
+    # one packed pass over the list; `row_scale[v]` = (image rows, event rows) to attenuate in video v, or None
+    def _pass(self, row_scale=None):
+        probs, wi_rows, we_rows = [], [], []
+        wi_dim = we_dim = None
+        with torch.no_grad():
+            for batch in self.batches:
+                dts = {self.videos[v][m].dtype for v in batch for m in (0, 1)}
+                dt = torch.float32 if len(dts) > 1 else next(iter(dts))
+                img = torch.cat([self.videos[v][0].to(dt) for v in batch]).to(self.device)
+                ev = torch.cat([self.videos[v][1].to(dt) for v in batch]).to(self.device)
+                valid, off = [], 0
+                for v in batch:
+                    nch, n = self.videos[v][0].shape[0], self.videos[v][2]
+                    if row_scale is not None:
+                        for x, idx in ((img, row_scale[v][0]), (ev, row_scale[v][1])):
+                            if idx is not None and idx.numel():
+                                blk = x[off:off + nch]
+                                blk[:, idx.to(self.device)] *= 0.01
+                    valid.append(torch.arange(off * self.T, off * self.T + n, device=self.device))
+                    off += nch
+                valid = torch.cat(valid)
+                out = self.model(img, ev, None, None, None)
+                D = out['w_i'].shape[-1]
+                probs.append(torch.sigmoid(out['logits'].reshape(-1)[valid]).float())
+                wi = out['w_i'].reshape(-1, D)[valid].float()
+                we = out['w_e'].reshape(-1, D)[valid].float()
+                wi_rows.append(wi.mean(dim=1))
+                we_rows.append(we.mean(dim=1))
+                si, se = wi.double().sum(dim=0), we.double().sum(dim=0)
+                wi_dim = si if wi_dim is None else wi_dim + si
+                we_dim = se if we_dim is None else we_dim + se
+        return {"p": torch.cat(probs), "wi_row": torch.cat(wi_rows), "we_row": torch.cat(we_rows),
+                "wi_dim": wi_dim / self.total, "we_dim": we_dim / self.total}
+
+    def clean(self):
+        if self._clean is None:
+            self._clean = self._pass()
+            self.clean_passes += 1
+        return self._clean
+
+    def level(self, sigma_img=0, sigma_ev=0) -> SweepResult:
+        c = self.clean()
+        k_img, k_ev = int(self.T * sigma_img), int(self.T * sigma_ev)
+        draws = []
+        for _ in self.videos:        # the reference's draw order: per video, image then event; no draw for a zero sigma
+            di = torch.randperm(self.T)[:k_img] if sigma_img else None
+            de = torch.randperm(self.T)[:k_ev] if sigma_ev else None
+            draws.append((di, de))
+        n = self._pass(draws)
+        rep = self.repeat
+        yc, yn = c["p"].double(), n["p"].double()
+        brier = ((yn[:, None] - self.gt) ** 2).mean()
+        eps = 1e-8
+        pc, qn = yc.clamp(eps, 1 - eps), yn.clamp(eps, 1 - eps)
+        kl = (pc * torch.log(pc / qn) + (1 - pc) * torch.log((1 - pc) / (1 - qn))).mean()
+        auc, ap = device_auc_ap(n["p"], self.gt, rep)
+        wi, we = n["wi_row"].double(), n["we_row"].double()
+        P, N = self.pos.sum(), (rep - self.pos).sum()
+        stats = torch.stack([brier, kl, wi.mean(), we.mean(), (wi * self.pos).sum() / P, (we * self.pos).sum() / P,
+                             (wi * (rep - self.pos)).sum() / N, (we * (rep - self.pos)).sum() / N]).cpu().tolist()
+        return SweepResult((stats[0], stats[1], stats[2], stats[3], auc, ap, stats[4], stats[5], stats[6], stats[7],
+                            (c["wi_dim"] - n["wi_dim"]).float().cpu(), (c["we_dim"] - n["we_dim"]).float().cpu()))
+
+
+def run_perturbation_test(args, model, loader, gt, device, sigma_img=0, sigma_ev=0, clean_cache: Optional[dict] = None,
+                          batch_chunks: int = 64) -> SweepResult:
+    """One level of the sweep with the call shape of the reference's `run_test(args, model, loader, gt, device,
+    sigma_img, sigma_ev)` (test2.py:35) and its 12-tuple.  `clean_cache` (a dict the caller keeps across levels) holds
+    the `PerturbationSweep`, so the unpacked list and the clean pass are shared by all levels."""
     model.eval()
-    maxlen = args.visual_length
-    repeat = 16
-    preds_clean, preds_noisy = [], []
-    w_img_orig, w_ev_orig, w_img_all, w_ev_all = [], [], [], []
-
-    def weights(out, length):
-        wi = out['w_i'].reshape(-1, out['w_i'].shape[-1])[:length].float().cpu()
-        we = out['w_e'].reshape(-1, out['w_e'].shape[-1])[:length].float().cpu()
-        return wi, we
-
-    with torch.no_grad():
-        for vid, (visuals, events, _, length) in enumerate(loader):
-            visuals = visuals.squeeze(0)
-            events = events.squeeze(0)
-            length = int(length)
-            if length < maxlen:
-                visuals = visuals.unsqueeze(0)
-                events = events.unsqueeze(0)
-            visuals = torch.nan_to_num(visuals).to(device)       # unconditional here (test2.py:59-60)
-            events = torch.nan_to_num(events).to(device)
-
-            if clean_cache is not None and vid in clean_cache:
-                p_c, wi_c, we_c = clean_cache[vid]
-            else:
-                out_c = model(visuals, events, None, None, torch.tensor([length]))
-                p_c = torch.sigmoid(out_c['logits'].reshape(-1)[:length]).float().cpu()
-                wi_c, we_c = weights(out_c, length)
-                if clean_cache is not None:
-                    clean_cache[vid] = (p_c, wi_c, we_c)
-            w_img_orig.append(wi_c)
-            w_ev_orig.append(we_c)
-
-            v_p, e_p = visuals.clone(), events.clone()
-            if sigma_img:
-                idx = torch.randperm(v_p.shape[1])[: int(v_p.shape[1] * sigma_img)]
-                v_p[:, idx] = v_p[:, idx] * 0.01
-            if sigma_ev:
-                idx = torch.randperm(e_p.shape[1])[: int(e_p.shape[1] * sigma_ev)]
-                e_p[:, idx] = e_p[:, idx] * 0.01
-            out_n = model(v_p, e_p, None, None, torch.tensor([length]))
-            p_n = torch.sigmoid(out_n['logits'].reshape(-1)[:length]).float().cpu()
-            wi_n, we_n = weights(out_n, length)
-            preds_clean.append(p_c)
-            preds_noisy.append(p_n)
-            w_img_all.append(wi_n)
-            w_ev_all.append(we_n)
-
-    yc = torch.cat(preds_clean).numpy()
-    yn = torch.cat(preds_noisy).numpy()
-    yc_rep, yn_rep = np.repeat(yc, repeat), np.repeat(yn, repeat)
-    gt_slice = gt[: len(yn_rep)]
-    w_img_all, w_ev_all = torch.cat(w_img_all), torch.cat(w_ev_all)
-    w_img_orig, w_ev_orig = torch.cat(w_img_orig), torch.cat(w_ev_orig)
-    w_img_change = w_img_orig.mean(0) - w_img_all.mean(0)
-    w_ev_change = w_ev_orig.mean(0) - w_ev_all.mean(0)
-    w_img = np.repeat(w_img_all.mean(1).numpy(), repeat)
-    w_ev = np.repeat(w_ev_all.mean(1).numpy(), repeat)
-    brier = brier_score(yn_rep, gt_slice)
-    kl = kl_divergence(yc_rep, yn_rep)
-    auc = roc_auc_score(gt_slice, yn_rep)
-    ap = average_precision_score(gt_slice, yn_rep)
-    return (brier, kl, w_img.mean(), w_ev.mean(), auc, ap, np.mean(w_img[gt_slice == 1]), np.mean(w_ev[gt_slice == 1]),
-            np.mean(w_img[gt_slice == 0]), np.mean(w_ev[gt_slice == 0]), w_img_change, w_ev_change)
+    sweep = clean_cache.get("sweep") if clean_cache is not None else None
+    if sweep is None:
+        sweep = PerturbationSweep(args, model, loader, gt, device, batch_chunks)
+        if clean_cache is not None:
+            clean_cache["sweep"] = sweep
+    return sweep.level(sigma_img, sigma_ev)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -57,10 +57,11 @@ def test_gemm_kernel_matches_fp64():
         assert err < 2e-4 * np.sqrt(K / 768.0) + 1e-5, (M, N, K, err)
 
 
-def test_three_gemm_tilings_are_bit_identical():
+def test_four_gemm_tilings_are_bit_identical():
     """The library picks the 128x256 ring kernel when its grid fills the chip, the 128x128 kernel for mid-size
-    grids and a 64x64-tile kernel for small M; all sum k in the same order, so the same rows give the same
-    bits whatever M they arrive in (this is what makes micro-batching and cross-video packing exact)."""
+    grids, a 64x64-tile kernel for small M and a 32x32-tile kernel on 16x16x4 MFMAs for the per-video pattern
+    (M = 256 .. ~1500); all sum k in the same order, so the same rows give the same bits whatever M they arrive in
+    (this is what makes micro-batching and cross-video packing exact)."""
     lib = iefvad_amd.lib.load_library()
     rng = np.random.default_rng(1)
     M, N, K = 16384, 768, 768
@@ -76,12 +77,29 @@ def test_three_gemm_tilings_are_bit_identical():
 
     t256 = gemm(A)                             # 128 x 3 = 384 blocks of 128x256  -> ring kernel
     t128 = gemm(A[:8192].contiguous())         # 64 x 6 = 384 blocks of 128x128   -> double-buffer kernel
-    t64 = gemm(A[1024:1280].contiguous())      # 2 x 6 blocks                      -> small-tile kernel
+    t64 = gemm(A[2048:4096].contiguous())      # 32 x 12 = 384 blocks of 64x64    -> small-tile kernel
+    t32 = gemm(A[1024:1280].contiguous())      # 4 x 12 = 48 blocks of 64x64 < 320 -> 32x32 tiles, 16x16x4 MFMA
+    t32b = gemm(A[4096:5376].contiguous())     # M = 1280: 240 blocks of 64x64     -> 32x32 tiles
     torch.cuda.synchronize()
     assert torch.equal(t256[:8192], t128)
-    assert torch.equal(t256[1024:1280], t64)
+    assert torch.equal(t256[2048:4096], t64)
+    assert torch.equal(t256[1024:1280], t32)
+    assert torch.equal(t256[4096:5376], t32b)
     ref = A[:256].double().cpu() @ W.double().cpu().t() + b.double().cpu()
     assert (t256[:256].double().cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_per_video_sized_forwards_equal_rows_of_a_large_batch():
+    """B = 1, 2, 3, 5 forwards (32x32-tile GEMMs, every epilogue: qkv scale, residual, heads split, relu, refine)
+    against the same chunks inside a B = 40 batch (64x64 / 128x128 / ring kernels): all eight outputs bit-identical."""
+    sd = synth.make_state_dict(91, 768, 2, 3)
+    img, ev = synth.make_inputs(92, 40)
+    model = make_model(2, 3, 0.5, "StudentT", 8, sd)
+    big = run(model, img, ev)
+    for lo, n in ((0, 1), (7, 2), (20, 3), (33, 5)):
+        part = run(model, img[lo:lo + n], ev[lo:lo + n])
+        for k in iefvad_amd.OUTPUT_KEYS:
+            assert np.array_equal(part[k], big[k][lo:lo + n]), (k, lo, n)
 
 
 @pytest.mark.parametrize("name", H.golden_cases())

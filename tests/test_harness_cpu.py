@@ -124,7 +124,8 @@ def test_perturbation_sweep_reproduces_reference_run_test(golden_dir):
         assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), tag
         assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
         assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
-    assert len(cache) == len(lengths)      # the clean forwards ran once, not once per level
+    assert cache["sweep"].clean_passes == 1      # the clean pass ran once, not once per level
+    assert r.auc == r[4] and r.w_ev_change is r[11]
 
 
 def test_streaming_file_pipeline_matches_per_video_loop(config1):

@@ -31,4 +31,6 @@ for outputs in ("scores", "full"):
                 o = m(x, y, None, None, None)
             host = (time.perf_counter() - t) / n
             torch.cuda.synchronize()
-        print(f"outputs={outputs:6s} B={B:3d}: {dt*1e3:8.3f} ms per forward (host enqueue {host*1e3:.3f} ms), {B*256/dt:,.0f} snippets/s")
+            m(x, y, None, None, None, timed=True)
+            st = {k: round(v, 4) for k, v in m.last_stage_times.items() if k.endswith("_ms")}
+        print(f"outputs={outputs:6s} B={B:3d}: {dt*1e3:8.3f} ms per forward (host enqueue {host*1e3:.3f} ms), {B*256/dt:,.0f} snippets/s  stages {st}")
