@@ -52,7 +52,7 @@ GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
-GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_kernel",
+GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_pipe_kernel",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -352,16 +352,15 @@ def main():
         return (torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45,
                 torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45)
 
-    comm = None
-    gather_impl = None
+    state = {"comm": None, "gather": None}
     if world > 1 and backend == "nccl":
         try:
-            comm = harness.ScoreComm(dev)
-            gather_impl = "iefvad_gather_scores (libiefvad -> librccl ncclAllGather on the forward's stream)"
+            state["comm"] = harness.ScoreComm(dev)
+            state["gather"] = "iefvad_gather_scores (libiefvad -> librccl ncclAllGather on the forward's stream)"
         except Exception as e:      # keep the measurement alive on RCCL through torch.distributed; say so in the line
-            gather_impl = f"torch.distributed all_gather_into_tensor (iefvad_comm_create failed: {e})"
+            state["gather"] = f"torch.distributed all_gather_into_tensor (iefvad_comm_create failed: {e})"
     elif world > 1:
-        gather_impl = "torch.distributed gloo (scores staged through the host)"
+        state["gather"] = "torch.distributed gloo (scores staged through the host)"
 
     def timed_run(img, ev, first, counts, steps, warmup):
         """Contract timing: `warmup` untimed steps, barrier + sync, exactly `steps` steps, sync + barrier, MAX over
@@ -379,8 +378,13 @@ def main():
             else:       # --plumbing-only: the global snippet indices of this rank's shard
                 scores = torch.arange(first * T, (first + counts[rank]) * T, dtype=torch.float32)
             if world > 1:
-                if comm is not None:
-                    scores = comm.gather(scores, snips)
+                if state["comm"] is not None:
+                    try:
+                        scores = state["comm"].gather(scores, snips)
+                    except RuntimeError as e:     # an enqueue error is symmetric across ranks: all of them switch
+                        state["comm"] = None
+                        state["gather"] = f"torch.distributed all_gather_into_tensor (iefvad_gather_scores failed: {e})"
+                        scores = harness.gather_scores(scores, counts=snips)
                 elif backend == "nccl":
                     scores = harness.gather_scores(scores, counts=snips)
                 else:
@@ -457,9 +461,10 @@ def main():
             line["plumbing_only"] = "no forward ran: fabricated scores, launcher / shard / gather / timing self-test"
             line["gathered_in_order"] = in_order
         if world > 1:
+            comm = state["comm"]
             line["rccl_ranks"] = comm.nranks if comm is not None else (dist.get_world_size() if backend == "nccl" else 0)
             line["dist_backend"] = backend
-            line["gather"] = gather_impl
+            line["gather"] = state["gather"]
             line["gathered_scores"] = gathered
             if weak is not None:
                 line["weak_scaling"] = weak
@@ -475,8 +480,8 @@ def main():
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)
-    if comm is not None:
-        comm.close()
+    if state["comm"] is not None:
+        state["comm"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

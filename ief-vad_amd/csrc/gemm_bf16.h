@@ -50,6 +50,7 @@ struct GemmBArgs {
     float alpha;
     int qcols;
     int wplane;          // split kernel (gemm_split.h): bytes between the three bf16 planes of W
+    int stagger;         // ring kernels: the second resident workgroup of each CU starts `stagger` x 8128 cycles late
 };
 
 #define GEMMB_BK 64                 // bf16 elements per k-tile (128 bytes per row)
@@ -336,12 +337,13 @@ __device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const 
 // 16 cycles -- the same reads, FLOPs and cycles as MODE 0 -- but the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md, DVFS item 7; measured here: see DESIGN.md).  Its LDS image uses the chunk swizzle
 // G[(row>>2)&3], G = {2,0,1,3}, which makes the (row, q) access pattern of the 16x16 fragment conflict-free.
-enum { T256_BF16_32 = 0, T256_F32 = 1, T256_BF16_16 = 2 };
+enum { T256_BF16_32 = 0, T256_F32 = 1, T256_BF16_16 = 2, T256_BF16_16P = 3 };   // 3 = 2 with the pinned issue order below
 
 template <int MODE>
 __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* smem) {
     constexpr bool F32 = (MODE == T256_F32);
-    constexpr bool MF16 = (MODE == T256_BF16_16);
+    constexpr bool MF16 = (MODE == T256_BF16_16 || MODE == T256_BF16_16P);
+    constexpr bool PIPE = (MODE == T256_BF16_16P);
     constexpr int EB = F32 ? 4 : 2;                     // bytes per operand element
     constexpr int BKE = 64 / EB;                        // elements per k-tile row (64 bytes)
     const GemmBProblem& P = args.p[blockIdx.z];
@@ -355,6 +357,17 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i = lane & 31, h = lane >> 5;
+
+    // De-phasing.  All workgroups of a launch start together and take the same time, so chip-wide every main loop
+    // (matrix pipe busy, HBM idle) and every epilogue (128 KB of stores per workgroup: HBM saturated, matrix pipe idle)
+    // coincide.  The launch's first 512 workgroups are the two residents of each CU; the second 256 of them (dispatch
+    // order is linear in blockIdx -- an observed property used for speed only) wait about half a tile time once, and
+    // from then on one resident of a CU stores while the other multiplies.
+    if (args.stagger > 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+        if (lin >= 256 && lin < 512)
+            for (int w = 0; w < args.stagger; ++w) __builtin_amdgcn_s_sleep(127);
+    }
 
     // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3
     const int srow = t >> 2, sch = t & 3;
@@ -439,6 +452,46 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
         }                                                                                                   \
     }
 
+
+    // ---- MODE 3: the k-tile of MODE 2 with its issue order pinned (sched_group_barrier).  A k-tile is 32 MFMAs of 16
+    // cycles per wave; in MODE 2 the wave first issues its six LDS-DMA instructions of tile kt+2 (60-180 cycles EACH when
+    // the vector-memory queue is busy), then twelve fragment reads, then the MFMAs -- with two waves per SIMD in lockstep
+    // the matrix pipe idles through both preambles.  Here the wave reads ga[0..3], gb[0..1], and every step b (4 MFMAs of
+    // column tile b) carries one fragment read (gb[b+2]) and, for b < 6, ONE of the six DMA instructions between its
+    // MFMAs, so the matrix pipe has work from ~100 cycles after the barrier until the end of the tile.
+#define GB2_DMA1(n_, tile, slotbase)                                                                       \
+    {                                                                                                      \
+        float* Ad = smem + (slotbase) + wbase;                                                             \
+        float* Wd = Ad + GB2_BM * 16;                                                                      \
+        const int kk = (tile) * BKE;                                                                       \
+        if ((n_) < 2) GLDS16(rsA, voA, (64 * (n_) * lda + kk) * EB, Ad + 64 * (n_) * 16);                  \
+        else GLDS16(rsW, voW, (64 * ((n_) - 2) * K + kk) * EB, Wd + 64 * ((n_) - 2) * 16);                 \
+    }
+#define GB2_PSTEP(b_, DMA_)                                                                                \
+    {                                                                                                      \
+        if ((b_) + 2 < 8) gb[((b_) + 2) & 7] = *(const f32x4*)(S + b16 + (((b_) + 2) & 7) * 16 * 16);      \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                      \
+            acc16[a][b_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                        \
+                __builtin_bit_cast(bf16x8, ga[a]), __builtin_bit_cast(bf16x8, gb[b_]), acc16[a][b_], 0, 0, 0); \
+        if (DMA_) { GB2_DMA1(b_, dma_tile, dma_slot) }                                                     \
+        if ((b_) + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                 \
+        if (DMA_) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                 \
+    }
+#define GB2_COMPUTE_PIPE(slotbase, DMA_)                                                                   \
+    {                                                                                                      \
+        const float* S = smem + (slotbase);                                                                \
+        f32x4 ga[4], gb[8];                                                                                \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) ga[x] = *(const f32x4*)(S + a16 + x * 16 * 16);      \
+        gb[0] = *(const f32x4*)(S + b16);                                                                  \
+        gb[1] = *(const f32x4*)(S + b16 + 16 * 16);                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                 \
+        GB2_PSTEP(0, DMA_) GB2_PSTEP(1, DMA_) GB2_PSTEP(2, DMA_) GB2_PSTEP(3, DMA_)                        \
+        GB2_PSTEP(4, DMA_) GB2_PSTEP(5, DMA_) GB2_PSTEP(6, false) GB2_PSTEP(7, false)                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+
     const int nk = K / BKE;          // >= 2
     int s0 = 0, s1 = GB2_SLOT, s2 = 2 * GB2_SLOT;     // slot of tile kt, kt+1, kt+2 (float offsets), rotated each tile
     GB2_STAGE(0, s0)
@@ -449,6 +502,25 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int kt = 0;
+    if constexpr (PIPE) {
+        for (; kt + 2 < nk; ++kt) {
+            const int dma_tile = kt + 2, dma_slot = s2;   // s2 held tile kt-1: every wave passed the barrier after reading it
+            GB2_COMPUTE_PIPE(s0, true)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own DMAs of tile kt+1 landed; tile kt+2's six stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GB2_BARRIER();
+            const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
+        }
+        {
+            const int dma_tile = 0, dma_slot = 0;
+            (void)dma_tile; (void)dma_slot;
+            GB2_COMPUTE_PIPE(s0, false)                       // tile nk-2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GB2_BARRIER();
+            GB2_COMPUTE_PIPE(s1, false)                       // tile nk-1
+        }
+    } else {
     for (; kt + 2 < nk; ++kt) {
         GB2_STAGE(kt + 2, s2)                         // s2 held tile kt-1: every wave passed the barrier after reading it
         GB2_COMPUTE(s0)
@@ -462,6 +534,7 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     GB2_BARRIER();
     GB2_COMPUTE(s1)                                   // tile nk-1
+    }
 #ifdef GB2_CLOCK_DIAG
     if (threadIdx.x == 0 && P.C2) {   // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
         unsigned long long* dg = (unsigned long long*)P.C2 + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
@@ -469,6 +542,9 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
         dg[1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
     }
 #endif
+#undef GB2_COMPUTE_PIPE
+#undef GB2_PSTEP
+#undef GB2_DMA1
 #undef GB2_COMPUTE
 #undef GB2_STAGE
 #undef GLDS16
@@ -482,6 +558,12 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_t256_body<T256_BF16_16>(args, smem);
+}
+
+// MODE 3: the same k-tile with the issue order pinned (A/B candidate of tools/gemm_tune_bf16)
+__global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_pipe_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_t256_body<T256_BF16_16P>(args, smem);
 }
 
 // the same kernel on the 32x32x16 shape, kept for A/B runs in tools/gemm_tune_bf16

@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs a
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // tile kt visible to every wave; every wave is done with tile kt - 1
+        // raw s_barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it (an LDS-DMA is a pending LDS write)
+        // and drain the two or three k-tiles in flight on every k-tile
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // tile kt visible to every wave; every wave is done with tile kt - 1
+        asm volatile("" ::: "memory");
         if (kt + 3 < nk) GEMT_STAGE(kt + 3, (kt + 3) % GEMT_STAGES)      // slot of tile kt - 1: free since the barrier
         const float* S = smem + (kt % GEMT_STAGES) * GEMT_SLOT;
 #pragma unroll

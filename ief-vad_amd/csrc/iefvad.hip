@@ -93,6 +93,7 @@ struct iefvad_handle {
     _Float16* ref_w1h[IEFVAD_MAX_STEPS];    const float* ref_w1a[IEFVAD_MAX_STEPS];
     _Float16* ref_w2h[IEFVAD_MAX_STEPS];    const float* ref_w2a[IEFVAD_MAX_STEPS];
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
+    struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
 };
 static const int kAmaxTensors = 512, kAmaxActBase = 256;   // tensors with a running max: [0, 256) matrices, [256, 512) activations
 static const int kAmaxWords = kAmaxTensors * IEF_AMAX_FLOATS;
@@ -143,6 +144,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GB2_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e == hipSuccess)
@@ -167,6 +171,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
 }
 
 static void release_events(iefvad_handle* h);
+static void release_graphs(iefvad_handle* h);
 
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
@@ -176,6 +181,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
     release_events(h);
+    release_graphs(h);
     delete h;
 }
 
@@ -466,7 +472,7 @@ static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& 
     if (a.N % GB2_BN == 0 && a.M % GB2_BM == 0 && a.K % GB2_BK == 0 && a.K >= 2 * GB2_BK) {
         dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
         e = tm.begin(stage);
-        hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, a);   // pinned issue order: +1..3 %, same bits
     } else {
         if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMMB_BK)
             return fail("gemm(bf16): shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM,
@@ -787,9 +793,136 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// small batches: replay a captured hipGraph of the forward
+// ------------------------------------------------------------------------------------------------
+// The reference calls the model once per video (test.py:76-117): B = 1 .. a few chunks, ~31 kernels of a few microseconds
+// each.  Launched one by one they are host-bound (3-5 us of enqueue per launch).  For B <= cfg.graph_chunks the library
+// captures forward_impl once per (B, in_dtype, output set, workspace) on a private stream, with every caller-owned
+// pointer replaced by a library-owned staging buffer, and a call becomes: two device-to-device copies of the inputs,
+// ONE hipGraphLaunch on the caller's stream, and one copy per requested output.  Same kernels, same order: same bits.
+static const int kGraphDefaultChunks = 8, kGraphMaxChunks = 32, kGraphMaxEntries = 48;
+
+struct GraphEntry {
+    int B, in_dtype;
+    unsigned outmask;
+    void* workspace;
+    size_t workspace_bytes;
+    hipGraphExec_t exec;
+    unsigned long long last_use;
+};
+
+struct GraphCache {
+    hipStream_t cap_stream = nullptr;
+    char* in_buf = nullptr;      // img | ev staging, sized for max_chunks at 4 bytes per element
+    float* small_buf = nullptr;  // logits | w_i_mean | w_e_mean, max_chunks * T floats each
+    float* big_buf = nullptr;    // the seven [B*T, D] outputs (allocated on the first call that asks for one)
+    int max_chunks = 0;
+    unsigned long long clock = 0;
+    std::vector<GraphEntry> entries;
+};
+
+static void release_graphs(iefvad_handle* h) {
+    if (!h->graphs) return;
+    for (auto& e : h->graphs->entries) (void)hipGraphExecDestroy(e.exec);
+    if (h->graphs->cap_stream) (void)hipStreamDestroy(h->graphs->cap_stream);
+    if (h->graphs->in_buf) (void)hipFree(h->graphs->in_buf);
+    if (h->graphs->small_buf) (void)hipFree(h->graphs->small_buf);
+    if (h->graphs->big_buf) (void)hipFree(h->graphs->big_buf);
+    delete h->graphs;
+    h->graphs = nullptr;
+}
+
+static int graph_limit(const iefvad_handle* h) {
+    const int g = h->cfg.graph_chunks;
+    if (g < 0) return 0;
+    const int lim = g == 0 ? kGraphDefaultChunks : (g < kGraphMaxChunks ? g : kGraphMaxChunks);
+    const int mb = micro_batch(h);
+    return lim < mb ? lim : mb;          // a graphed call is a single micro-batch
+}
+
+static int forward_graphed(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
+                           size_t workspace_bytes, const iefvad_outputs* out, hipStream_t stream) {
+    static_assert(sizeof(iefvad_outputs) == 10 * sizeof(float*), "iefvad_outputs is ten pointers");
+    const size_t D = IEF_D, T = IEF_T;
+    if (!h->graphs) {
+        h->graphs = new (std::nothrow) GraphCache();
+        if (!h->graphs) return fail("iefvad_forward: out of host memory");
+    }
+    GraphCache& gc = *h->graphs;
+    if (!gc.cap_stream) {
+        HIP_TRY(hipSetDevice(h->device));
+        gc.max_chunks = graph_limit(h);
+        HIP_TRY(hipStreamCreateWithFlags(&gc.cap_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void**)&gc.in_buf, 2 * (size_t)gc.max_chunks * T * D * 4));
+        HIP_TRY(hipMalloc((void**)&gc.small_buf, 3 * (size_t)gc.max_chunks * T * sizeof(float)));
+    }
+    const size_t rows = (size_t)B * T, mrows = (size_t)gc.max_chunks * T;
+    float* const* of = (float* const*)out;               // fused logits image_mu event_mu image_logvar event_logvar w_i w_e w_i_mean w_e_mean
+    static const bool kBig[10] = {true, false, true, true, true, true, true, true, false, false};
+    unsigned outmask = 0;
+    bool any_big = false;
+    for (int i = 0; i < 10; ++i)
+        if (of[i]) { outmask |= 1u << i; any_big |= kBig[i]; }
+    if (any_big && !gc.big_buf) HIP_TRY(hipMalloc((void**)&gc.big_buf, 7 * mrows * D * sizeof(float)));
+    // staging addresses (fixed for the life of the handle, so every captured graph stays valid)
+    char* s_img = gc.in_buf;
+    char* s_ev = gc.in_buf + mrows * D * 4;
+    float* s_out[10];
+    {
+        int big = 0, small = 0;
+        for (int i = 0; i < 10; ++i)
+            s_out[i] = kBig[i] ? gc.big_buf + (size_t)(big++) * mrows * D : gc.small_buf + (size_t)(small++) * mrows;
+    }
+    GraphEntry* hit = nullptr;
+    for (auto& e : gc.entries)
+        if (e.B == B && e.in_dtype == in_dtype && e.outmask == outmask && e.workspace == workspace && e.workspace_bytes == workspace_bytes) hit = &e;
+    if (!hit) {
+        iefvad_outputs so;
+        float** sf = (float**)&so;
+        for (int i = 0; i < 10; ++i) sf[i] = of[i] ? s_out[i] : nullptr;
+        Timer tm;
+        HIP_TRY(hipStreamBeginCapture(gc.cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = forward_impl(h, s_img, s_ev, in_dtype, B, workspace, workspace_bytes, &so, gc.cap_stream, tm);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(gc.cap_stream, &graph);      // always end the capture, also after a failed launch
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (ce != hipSuccess || !graph) return fail("iefvad_forward: hipStreamEndCapture: %s", hipGetErrorString(ce));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail("iefvad_forward: hipGraphInstantiate: %s", hipGetErrorString(ie));
+        if ((int)gc.entries.size() >= kGraphMaxEntries) {                      // evict the least recently used graph
+            size_t lru = 0;
+            for (size_t i = 1; i < gc.entries.size(); ++i)
+                if (gc.entries[i].last_use < gc.entries[lru].last_use) lru = i;
+            (void)hipGraphExecDestroy(gc.entries[lru].exec);
+            gc.entries.erase(gc.entries.begin() + (long)lru);
+        }
+        gc.entries.push_back(GraphEntry{B, in_dtype, outmask, workspace, workspace_bytes, exec, 0});
+        hit = &gc.entries.back();
+    }
+    hit->last_use = ++gc.clock;
+    const size_t in_bytes = rows * D * in_elem_bytes(in_dtype);
+    HIP_TRY(hipMemcpyAsync(s_img, img, in_bytes, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s_ev, ev, in_bytes, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipGraphLaunch(hit->exec, stream));
+    for (int i = 0; i < 10; ++i)
+        if (of[i]) HIP_TRY(hipMemcpyAsync(of[i], s_out[i], rows * (kBig[i] ? D : 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
 extern "C" int iefvad_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
                               size_t workspace_bytes, const iefvad_outputs* out, void* stream) {
-    Timer tm;
+    if (h && out && img && ev && h->weights_set && B > 0 && B <= graph_limit(h) && workspace &&
+        workspace_bytes >= iefvad_workspace_bytes(h, B) && !(((uintptr_t)workspace | (uintptr_t)img | (uintptr_t)ev) & 15) &&
+        (in_dtype == IEFVAD_IN_F32 || in_dtype == IEFVAD_IN_F16 || in_dtype == IEFVAD_IN_BF16))
+        return forward_graphed(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream);
+    Timer tm;      // everything else, and every invalid argument (reported by forward_impl), takes the direct path
     return forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream, tm);
 }
 

@@ -35,7 +35,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("embed_dim", C.c_int32), ("seq_len", C.c_int32),
                 ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("num_steps", C.c_int32),
                 ("noise_model", C.c_int32), ("compute", C.c_int32), ("lambda_ref", C.c_float),
-                ("nu", C.c_float), ("epsilon", C.c_float), ("micro_batch", C.c_int32)]
+                ("nu", C.c_float), ("epsilon", C.c_float), ("micro_batch", C.c_int32), ("graph_chunks", C.c_int32)]
 
 
 class Weights(C.Structure):

@@ -112,6 +112,8 @@ class MMFMIL(nn.Module):
                    (only `logits` plus the per-row means `w_i_mean`, `w_e_mean`; nothing 768-wide
                    is written to HBM).
       micro_batch  chunks per internal pass of the library (0 = library default).
+      graph_chunks calls with B <= graph_chunks replay a cached hipGraph of the forward instead of launching its ~31
+                   kernels one by one (0 = library default, 8; negative = never).  Same bits either way.
       compute      "f32" (default): exact-fp32 MFMA projections, the parity mode;
                    "bf16": bf16 MFMA operands with fp32 accumulation in the dense projections and in the two
                    attention products; softmax, LayerNorm, the residual stream, the fusion and the refinement
@@ -127,7 +129,7 @@ class MMFMIL(nn.Module):
 
     def __init__(self, num_class: int, embed_dim: int, visual_length: int, visual_width: int, visual_head: int,
                  visual_layers: int, attn_window: int, prompt_prefix: int, prompt_postfix: int, device, args,
-                 *, outputs: str = "full", micro_batch: int = 0, compute: str = "f32"):
+                 *, outputs: str = "full", micro_batch: int = 0, compute: str = "f32", graph_chunks: int = 0):
         super().__init__()
         self.num_class = num_class
         self.visual_length = visual_length
@@ -147,6 +149,7 @@ class MMFMIL(nn.Module):
         self.outputs = outputs
         self.micro_batch = micro_batch
         self.compute = compute
+        self.graph_chunks = graph_chunks
         self._handle: Optional[C.c_void_p] = None
         self._handle_key = None
         self._weights_sig = None
@@ -178,7 +181,8 @@ class MMFMIL(nn.Module):
     def _ensure_handle(self, device: torch.device):
         t = self.temporal
         key = (device.index, t.embed_dim, self.visual_length, t.num_heads, t.num_layers, t.num_refinement_steps,
-               self._noise_code(), float(t.lambda_ref), float(t.nu), float(t.epsilon), int(self.micro_batch), self.compute)
+               self._noise_code(), float(t.lambda_ref), float(t.nu), float(t.epsilon), int(self.micro_batch), self.compute,
+               int(self.graph_chunks))
         if self._handle is not None and key == self._handle_key:
             return
         self._release()
@@ -187,7 +191,8 @@ class MMFMIL(nn.Module):
                           num_heads=t.num_heads, num_layers=t.num_layers, num_steps=t.num_refinement_steps,
                           noise_model=self._noise_code(),
                           compute=_lib.COMPUTE_CODES[self.compute], lambda_ref=float(t.lambda_ref),
-                          nu=float(t.nu), epsilon=float(t.epsilon), micro_batch=int(self.micro_batch))
+                          nu=float(t.nu), epsilon=float(t.epsilon), micro_batch=int(self.micro_batch),
+                          graph_chunks=int(self.graph_chunks))
         h = C.c_void_p()
         with torch.cuda.device(device):
             rc = lib.iefvad_create(C.byref(cfg), C.byref(h))

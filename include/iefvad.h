@@ -71,6 +71,10 @@ typedef struct iefvad_config {
     float nu;
     float epsilon;
     int32_t micro_batch;   /* chunks processed per internal pass; 0 = library default */
+    int32_t graph_chunks;  /* calls with B <= graph_chunks replay a cached hipGraph of the forward (the reference's
+                              per-video pattern, /root/reference/test.py:76-117: B = 1 .. a few chunks, 31 launches of a
+                              few microseconds each, host-bound when launched one by one); 0 = library default (8),
+                              negative = never.  Results are bit-identical to the direct launches. */
 } iefvad_config;
 
 /* Device pointers to the reference's state_dict tensors, fp32, laid out

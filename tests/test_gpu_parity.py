@@ -236,3 +236,32 @@ def test_non_finite_inputs_propagate_like_the_reference():
         assert np.abs(out[k][fin] - r[fin]).max() <= (H.TOL_LOGIT if k == "logits" else H.TOL_BIG), k
     assert np.isnan(out["logits"][1]).all() and np.isfinite(out["logits"][[0, 2]]).all()
     assert np.isfinite(out["event_mu"]).all()          # the event branch never saw the inf
+
+
+def test_graph_replay_is_bit_identical_to_direct_launches():
+    """Calls with B <= graph_chunks replay a cached hipGraph (inputs and outputs staged through library-owned buffers);
+    graph_chunks = -1 launches the same kernels one by one.  Same bits, for every output, every input dtype, repeated
+    calls with fresh tensors, interleaved batch sizes, and after a weight update."""
+    sd = synth.make_state_dict(93, 768, 2, 3)
+    img, ev = synth.make_inputs(94, 6)
+    direct = make_model(2, 3, 0.5, "StudentT", 8, sd, graph_chunks=-1)
+    graphed = make_model(2, 3, 0.5, "StudentT", 8, sd, graph_chunks=4)
+    lite = make_model(2, 3, 0.5, "StudentT", 8, sd, graph_chunks=4, outputs="scores")
+    for rep in range(2):
+        for lo, n in ((0, 1), (1, 3), (0, 1), (2, 4), (0, 6)):          # B = 6 > graph_chunks: direct path inside `graphed`
+            a = run(direct, img[lo:lo + n], ev[lo:lo + n])
+            b = run(graphed, img[lo:lo + n].copy(), ev[lo:lo + n].copy())
+            c = run(lite, img[lo:lo + n], ev[lo:lo + n])
+            for k in iefvad_amd.OUTPUT_KEYS:
+                assert np.array_equal(a[k], b[k]), (k, lo, n, rep)
+            assert np.array_equal(a["logits"], c["logits"])
+            assert np.array_equal(a["w_i"].mean(-1).astype(np.float32).shape, c["w_i_mean"].shape)
+    h16 = run(graphed, img[:2].astype(np.float16), ev[:2].astype(np.float16))
+    d16 = run(direct, img[:2].astype(np.float16), ev[:2].astype(np.float16))
+    for k in iefvad_amd.OUTPUT_KEYS:
+        assert np.array_equal(h16[k], d16[k]), k
+    with torch.no_grad():
+        for m in (direct, graphed):
+            m.temporal.classifier.bias.add_(0.25)
+    a, b = run(direct, img[:1], ev[:1]), run(graphed, img[:1], ev[:1])
+    assert np.array_equal(a["logits"], b["logits"])

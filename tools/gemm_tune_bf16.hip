@@ -15,6 +15,7 @@ struct Variant { const char* name; int kind; int epi; int nz; bool c32, c16; };
 
 static float time_variant(const Variant& v, GemmBArgs g, int iters) {
     g.epi = v.epi;
+    g.stagger = getenv("GB2_STAGGER") ? atoi(getenv("GB2_STAGGER")) : 0;
     if (v.epi == EPI_REFINE) g.alpha = 0.5f;
     for (int m = 0; m < 2; ++m) { if (!v.c32) g.p[m].C = nullptr; if (!v.c16) g.p[m].Cb = nullptr; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -23,6 +24,9 @@ static float time_variant(const Variant& v, GemmBArgs g, int iters) {
         if (v.kind == 2) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_m32_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        } else if (v.kind == 4) {
+            dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
         } else if (v.kind == 3) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
@@ -52,13 +56,17 @@ int main(int argc, char** argv) {
     CK(hipMemset(bias, 0, 2304 * 4)); CK(hipMemset(C, 0, (size_t)M * 2304 * 4));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_m32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"m32 bias  C32", 2, EPI_BIAS, 1, true, false},
                           {"m32 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"m32 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
                           {"m32 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"m32 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
                           {"m32 bias  C32 z=2", 2, EPI_BIAS, 2, true, false}, {"m32 none (no stores)", 2, EPI_BIAS, 1, false, false},
                           {"m16 bias  C32", 3, EPI_BIAS, 1, true, false}, {"m16 relu  C16 only", 3, EPI_BIAS_RELU, 1, false, true},
                           {"m16 refine C32+C16", 3, EPI_REFINE, 1, true, true}, {"m16 bias  C32 z=2", 3, EPI_BIAS, 2, true, false},
-                          {"m16 none (no stores)", 3, EPI_BIAS, 1, false, false}};
+                          {"m16 none (no stores)", 3, EPI_BIAS, 1, false, false},
+                          {"pipe bias  C32", 4, EPI_BIAS, 1, true, false}, {"pipe relu  C16 only", 4, EPI_BIAS_RELU, 1, false, true},
+                          {"pipe refine C32+C16", 4, EPI_REFINE, 1, true, true}, {"pipe bias  C32 z=2", 4, EPI_BIAS, 2, true, false},
+                          {"pipe none (no stores)", 4, EPI_BIAS, 1, false, false}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int ni = 0; ni < 2; ++ni) {
         GemmBArgs g; memset(&g, 0, sizeof(g));
@@ -75,6 +83,11 @@ int main(int argc, char** argv) {
             time_variant(vs[8], g, 1); CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
             double md = 0; for (size_t q = 0; q < c1.size(); ++q) { double d = fabs((double)c1[q] - c2[q]); if (d > md) md = d; }
             printf("N=%d: m16 vs v1: max abs diff %.3g (different fp32 summation order inside a k-tile)\n", g.N, md);
+            std::vector<float> c3((size_t)M * g.N);
+            CK(hipMemset(C, 0, c1.size() * 4));
+            time_variant(vs[13], g, 1); CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad3 = 0; for (size_t q = 0; q < c3.size(); ++q) bad3 += (c3[q] != c2[q]);
+            printf("N=%d: pipe vs m16: %zu mismatching elements of %zu\n", g.N, bad3, c3.size());
         }
         std::vector<std::vector<float>> t(nv);
         for (int r = 0; r < rounds; ++r)
