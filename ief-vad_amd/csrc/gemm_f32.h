@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_small_kernel(GemmArgs 
 // block tile, 4 waves as 2 x 2 of ONE 16 x 16 accumulator on v_mfma_f32_16x16x4_f32.  A launch has 4x the blocks of the
 // 64 x 64 kernel (a 256 x 768 projection: 192 blocks instead of 48 on 256 CUs) and a wave's dependent MFMA chain is
 // 192 x 40 cycles = 3.2 us instead of 384 x 64 = 10.2 us.  k-tiles are 1/3 the MFMA time of the 64 x 64 kernel's, shorter
-// than an L2 round trip, so the LDS ring has 4 slots filled three k-tiles ahead behind a counted s_waitcnt vmcnt.
+// than a round trip to the Infinity Cache (the weights of a forward, 94 MB, do not stay in the 4 MB L2), so the LDS ring
+// has 4 slots of 8 KB filled three k-tiles ahead behind a counted s_waitcnt vmcnt and a raw s_barrier.  Measured (rocprofv3,
+// M = 256, N = 768): 12-15 us per launch against 23 us for the 64 x 64 kernel; a k-tile takes ~1100 cycles for 320 of MFMA
+// chain -- LDS-DMA issue, fragment-read latency and the barrier of a workgroup that is alone on its CU; seven tiles ahead
+// (8 slots) did not help (17 us), so it is not memory latency.
 //
 // Same summation order per output element as the 32x32x2 kernels -- k = 8s + {0,4,1,5,2,6,3,7}, k-tiles ascending -- so
 // the results are bit-identical to them: MFMA j (j = 0, 1) of the 8-group s takes from lane group q = lane >> 4 the
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_small_kernel(GemmArgs 
 // ------------------------------------------------------------------------------------------------------------
 #define GEMT_BM 32
 #define GEMT_BN 32
-#define GEMT_STAGES 4
+#define GEMT_STAGES 4                                    // ring slots; GEMT_STAGES - 1 k-tiles are in flight (8 slots: 15.2 -> 17.3 us)
 #define GEMT_SLOT ((GEMT_BM + GEMT_BN) * GEMM_BK)        // floats per ring slot: 64 rows x 128 B = 8 KB
 
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs args) {
@@ -363,21 +367,30 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs a
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int nk = K / GEMM_BK;
-    // prologue: k-tiles 0, 1, 2 in flight (nk >= 3 for every K the library uses; guarded for smaller K)
-    GEMT_STAGE(0, 0)
-    if (nk > 1) GEMT_STAGE(1, 1)
-    if (nk > 2) GEMT_STAGE(2, 2)
+    // prologue: k-tiles 0 .. GEMT_STAGES - 2 in flight
+#pragma unroll
+    for (int p = 0; p < GEMT_STAGES - 1; ++p)
+        if (p < nk) GEMT_STAGE(p, p)
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed: each tile is 2 instructions per wave, issued in order
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt must have landed: each tile is 2 instructions per wave, issued in order; the tiles after it stay in flight
+        {
+            const int ahead = nk - 1 - kt < GEMT_STAGES - 2 ? nk - 1 - kt : GEMT_STAGES - 2;     // tiles issued after tile kt
+            switch (ahead) {
+                case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        }
         // raw s_barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it (an LDS-DMA is a pending LDS write)
         // and drain the two or three k-tiles in flight on every k-tile
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();          // tile kt visible to every wave; every wave is done with tile kt - 1
         asm volatile("" ::: "memory");
-        if (kt + 3 < nk) GEMT_STAGE(kt + 3, (kt + 3) % GEMT_STAGES)      // slot of tile kt - 1: free since the barrier
+        if (kt + GEMT_STAGES - 1 < nk) GEMT_STAGE(kt + GEMT_STAGES - 1, (kt + GEMT_STAGES - 1) % GEMT_STAGES)   // slot of tile kt - 1: free since the barrier
         const float* S = smem + (kt % GEMT_STAGES) * GEMT_SLOT;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
