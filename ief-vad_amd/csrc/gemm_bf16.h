@@ -247,6 +247,17 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // The wave tile is (32 PASSES) rows x 128 columns with origin (wrow0, wcol0) inside the block tile at (m0, n0).
 // `cscale` multiplies the accumulators before the bias (1 except in the fp16x3 path, where it undoes the operand scales);
 // `amax_out` (nullable) receives the running max |value written to C|.
+// Result stores of the ring / split kernels.  GB2_NT_STORES=1 marks them non-temporal (global_store ... nt): a launch writes
+// 0.8-4.8 GB that no workgroup of the SAME launch reads again, while the A panels and W planes its co-resident workgroups
+// share must stay in the 4 MB L2 of their XCD.
+#ifndef GB2_NT_STORES
+#define GB2_NT_STORES 1      // bf16 ring kernel +3..6 % with fp32 results, split kernels +0..1 % (profiles/r02_gemm_nt_stores.log)
+#endif
+#if GB2_NT_STORES
+#define GB2_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define GB2_STORE(ptr, val) (*(ptr) = (val))
+#endif
 template <bool MF16, int PASSES>
 __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const GemmBProblem& P, float* smem, int m0, int n0,
                                                    int wrow0, int wcol0, f32x16 (&acc)[PASSES][4],
@@ -305,12 +316,12 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
             } else if (epi == EPI_BIAS_RESID) v = v + res[u];
             else if (epi == EPI_REFINE) v = res[u] - alpha * v;
             const size_t o = (size_t)(mrow + 2 * u) * ldc + nn;
-            if (C32) *(f32x4*)(C32 + o) = v;
+            if (C32) GB2_STORE((f32x4*)(C32 + o), v);
             if (C16) {
                 bf16x4 w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
-                *(bf16x4*)(C16 + o) = w;
+                GB2_STORE((bf16x4*)(C16 + o), w);
             }
             if (amax_out) {
 #pragma unroll

@@ -202,6 +202,49 @@ def _unpack_item(item, maxlen, dataset, label_map):
     return img, ev, cls, length
 
 
+class _PinnedStager:
+    """Host -> device hand-over of the evaluation loop.  The reference does `img.to(device)` on pageable tensors
+    (test.py:90-95), a synchronous staged copy at a few GB/s that blocks the host for longer than a one-chunk forward
+    takes on the device.  Here the chunks of a forward are gathered into one of two reusable PINNED buffers (one host
+    memcpy, which also does the torch.cat of a packed batch) and sent with an asynchronous copy on the current stream;
+    a buffer is reused only after the event behind its last copy has completed."""
+
+    def __init__(self, device, slots: int = 2):
+        self.device = torch.device(device)
+        self.bufs = [[None, None] for _ in range(slots)]      # per slot: image / event pinned byte buffers
+        self.events = [None] * slots
+        self.turn = 0
+
+    def _buffer(self, slot, m, nbytes):
+        b = self.bufs[slot][m]
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, pin_memory=True)
+            self.bufs[slot][m] = b
+        return b
+
+    def upload(self, imgs, evs, dt):
+        slot = self.turn
+        self.turn = (self.turn + 1) % len(self.bufs)
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        out = []
+        for m, parts in enumerate((imgs, evs)):
+            n = sum(int(p.shape[0]) for p in parts)
+            shape = (n,) + tuple(parts[0].shape[1:])
+            count = n * int(parts[0].shape[1]) * int(parts[0].shape[2])
+            esize = torch.empty(0, dtype=dt).element_size()
+            host = self._buffer(slot, m, count * esize)[:count * esize].view(dt).view(shape)
+            off = 0
+            for p in parts:
+                host[off:off + p.shape[0]].copy_(p)          # casts when the batch was widened
+                off += p.shape[0]
+            out.append(host.to(self.device, non_blocking=True))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[slot] = ev
+        return out[0], out[1]
+
+
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
                  label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True):
     """Per-video sigmoid scores and mean fusion weights, in loader order.
@@ -223,6 +266,8 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     spans: List[Tuple[int, int]] = []          # (offset into the concatenated device vectors, valid length) per video
     total = 0
 
+    stager = _PinnedStager(device) if torch.device(device).type == 'cuda' else None
+
     def flush():
         nonlocal pend, pend_chunks, total
         if not pend:
@@ -232,8 +277,11 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         # to fp32 here rather than narrowed to the first tensor's type
         dts = {p[0].dtype for p in pend} | {p[1].dtype for p in pend}
         dt = torch.float32 if len(dts) > 1 else pend[0][0].dtype
-        img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
-        ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device, non_blocking=True)
+        if stager is not None:
+            img, ev = stager.upload([p[0] for p in pend], [p[1] for p in pend], dt)
+        else:
+            img = torch.cat([p[0].to(dt) for p in pend], dim=0).to(device)
+            ev = torch.cat([p[1].to(dt) for p in pend], dim=0).to(device)
         out = model(img, ev, None, None, None)
         logits = out['logits'].reshape(-1)
         if 'w_i_mean' in out:
