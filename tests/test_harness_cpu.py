@@ -179,3 +179,20 @@ def test_pipeline_rejects_event_file_of_another_length(tmp_path):
     pipe = harness.FeatureFilePipeline([p], ["Normal"], 256, "event_thr_10", "cpu")
     with pytest.raises(ValueError, match="do not match"):
         list(pipe.batches())
+
+
+def test_has_nan_matches_isnan_any():
+    """The evaluation loop's NaN presence check (conditional nan_to_num, test.py:90-95) is a sum first and an exact scan
+    only when the sum is NaN; +inf and -inf together (NaN sum, no NaN element) must not count as a NaN."""
+    x = torch.randn(2, 256, 768)
+    assert not harness._has_nan(x)
+    x[1, 3, 4] = float("nan")
+    assert harness._has_nan(x)
+    y = torch.randn(2, 256, 768)
+    y[0, 0, 0], y[0, 0, 1] = float("inf"), float("-inf")
+    assert not harness._has_nan(y) and not torch.isnan(y).any()
+    h = (torch.randn(2, 256, 768) * 60000).half()            # fp16 values whose fp16 sum would overflow
+    assert not harness._has_nan(h)
+    h[0, 0, 0] = float("nan")
+    assert harness._has_nan(h)
+    assert not harness._has_nan(torch.zeros(3, dtype=torch.int32))
