@@ -427,3 +427,4 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs a
         Cb[o] = v;
     }
 }
+
