@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_small_kernel(GemmArgs 
 // the 16-byte chunk 2s + (q & 1) of its row (the same image and swizzle as the other kernels; conflict-free for this
 // pattern too: the eight even rows of a 16-lane group land on chunk ^ {0..7}) and picks elements (q >> 1) + 2j.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef GEMT_EXP          // tools/gemm_tune_tiny timing experiments (wrong results when non-zero): 1 no DMA in the loop,
+#define GEMT_EXP 0        // 2 no barrier, 4 no MFMA, 8 no fragment reads (bit mask)
+#endif
 #define GEMT_BM 32
 #define GEMT_BN 32
 #define GEMT_STAGES 4                                    // ring slots; GEMT_STAGES - 1 k-tiles are in flight (8 slots: 15.2 -> 17.3 us)
@@ -363,46 +366,100 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_f32_tiny_kernel(GemmArgs a
     const int arow = wr * 16 + r16, brow = wc * 16 + r16;
     const int fsw = (r16 >> 1) & 7;                                  // (row >> 1) & 7 of both fragment rows (16 | 16 wr)
     const int aoff = arow * GEMM_BK, boff = GEMT_BM * GEMM_BK + brow * GEMM_BK;
-    const bool hi = (q >> 1) != 0;
-
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int nk = K / GEMM_BK;
-    // prologue: k-tiles 0 .. GEMT_STAGES - 2 in flight
+    const int nk = K / GEMM_BK;                 // even (the launcher requires K % 64 == 0)
+    // Software pipeline across k-tiles: while the eight dependent MFMAs of tile kt run (320 cycles) on fragments already
+    // in registers, the wave reads the fragments of tile kt+1 from LDS, so no MFMA ever waits for a ds_read; with the reads
+    // inside the tile (first build) a k-tile cost ~1100 cycles: 4 x exposed read latency + DMA issue + barrier skew.
+    //   iteration kt:  wait (own pieces of tile kt+1 landed)  ->  barrier  ->  issue the DMA of tile kt+3 (slot of tile
+    //                  kt-1, whose readers finished an iteration ago)  ->  read fragments of tile kt+1  ->  MFMAs of tile kt
+    // A lane needs elements (q >> 1) and (q >> 1) + 2 of chunk 2g + (q & 1) of its row: two dword reads at a fixed distance
+    // of 2 floats (ds_read2_b32), NOT a ds_read_b128 plus selects -- fragment sets that live across loop iterations and are
+    // indexed by a lane-dependent element made hipcc build 16-way v_cndmask chains.
+    float pa0[8], pb0[8], pa1[8], pb1[8];      // fragment sets of the even / odd k-tiles (loop unrolled by two: no moves)
+    int foff[4];
 #pragma unroll
-    for (int p = 0; p < GEMT_STAGES - 1; ++p)
-        if (p < nk) GEMT_STAGE(p, p)
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed: each tile is 2 instructions per wave, issued in order; the tiles after it stay in flight
-        {
-            const int ahead = nk - 1 - kt < GEMT_STAGES - 2 ? nk - 1 - kt : GEMT_STAGES - 2;     // tiles issued after tile kt
-            switch (ahead) {
-                case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
-        }
-        // raw s_barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it (an LDS-DMA is a pending LDS write)
-        // and drain the two or three k-tiles in flight on every k-tile
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // tile kt visible to every wave; every wave is done with tile kt - 1
-        asm volatile("" ::: "memory");
-        if (kt + GEMT_STAGES - 1 < nk) GEMT_STAGE(kt + GEMT_STAGES - 1, (kt + GEMT_STAGES - 1) % GEMT_STAGES)   // slot of tile kt - 1: free since the barrier
-        const float* S = smem + (kt % GEMT_STAGES) * GEMT_SLOT;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ch = ((2 * s + (q & 1)) ^ fsw) << 2;
-            const f32x4 fa = *(const f32x4*)(S + aoff + ch);
-            const f32x4 fb = *(const f32x4*)(S + boff + ch);
-            const float a0 = hi ? fa[1] : fa[0], a1 = hi ? fa[3] : fa[2];
-            const float b0 = hi ? fb[1] : fb[0], b1 = hi ? fb[3] : fb[2];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-        }
+    for (int g = 0; g < 4; ++g) foff[g] = (((2 * g + (q & 1)) ^ fsw) << 2) + (q >> 1);
+#define GEMT_READ(PA, PB, kt_)                                                            \
+    {                                                                                     \
+        const float* S = smem + ((kt_) % GEMT_STAGES) * GEMT_SLOT;                        \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                   \
+            PA[2 * g] = S[aoff + foff[g]];                                                \
+            PA[2 * g + 1] = S[aoff + foff[g] + 2];                                        \
+            PB[2 * g] = S[boff + foff[g]];                                                \
+            PB[2 * g + 1] = S[boff + foff[g] + 2];                                        \
+        }                                                                                 \
     }
+#define GEMT_MFMA(PA, PB)                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                         \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(PA[e], PB[e], acc, 0, 0, 0);
+#define GEMT_RAW_BARRIER()                    \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");
+    // (raw s_barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it -- an LDS-DMA is a pending LDS write --
+    // and drain the ring on every k-tile)
+    // One k-tile: the eight MFMAs form one dependent chain (40 cycles each, 8 of them issue), so everything else of the
+    // iteration is issued INSIDE the chain, pinned with sched_barrier: the two LDS-DMA instructions of tile kt+3 behind
+    // MFMAs 0 and 1, the fragment reads of tile kt+1 (group g behind MFMA 2 + g).  Issued in front of the chain they cost
+    // their full issue time (ablation, tools/gemm_tune_tiny: reads 2.6 us, DMA + barrier 3.5 us of a 13.4 us launch whose MFMA
+    // chain is 3.2 us).
+#define GEMT_SB() __builtin_amdgcn_sched_barrier(0)
+#define GEMT_READ1(PA, PB, S_, g_)                                                        \
+    {                                                                                     \
+        PA[2 * (g_)] = (S_)[aoff + foff[g_]];                                             \
+        PA[2 * (g_) + 1] = (S_)[aoff + foff[g_] + 2];                                     \
+        PB[2 * (g_)] = (S_)[boff + foff[g_]];                                             \
+        PB[2 * (g_) + 1] = (S_)[boff + foff[g_] + 2];                                     \
+    }
+#define GEMT_M(PA, PB, e_) if (!(GEMT_EXP & 4)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(PA[e_], PB[e_], acc, 0, 0, 0);
+#define GEMT_ITER(CUR_A, CUR_B, NXT_A, NXT_B, kt_)                                        \
+    {                                                                                     \
+        const bool nxt = (kt_) + 1 < nk, dma = (kt_) + 3 < nk && !(GEMT_EXP & 1);         \
+        const float* Sn = smem + (((kt_) + 1) % GEMT_STAGES) * GEMT_SLOT;                 \
+        float* Dd = smem + (((kt_) + 3) % GEMT_STAGES) * GEMT_SLOT + uw * 8 * GEMM_BK;    \
+        if (nxt) {                                                                        \
+            if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         \
+            if (!(GEMT_EXP & 2)) { GEMT_RAW_BARRIER() }                                   \
+        }                                                                                 \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 0) GEMT_SB();                                     \
+        if (dma) GLDS16(rsA, voA, ((kt_) + 3) * GEMM_BK * 4, Dd);                         \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 1) GEMT_SB();                                     \
+        if (dma) GLDS16(rsW, voW, ((kt_) + 3) * GEMM_BK * 4, Dd + GEMT_BM * GEMM_BK);     \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 2) GEMT_SB();                                     \
+        if (nxt && !(GEMT_EXP & 8)) GEMT_READ1(NXT_A, NXT_B, Sn, 0)                       \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 3) GEMT_SB();                                     \
+        if (nxt && !(GEMT_EXP & 8)) GEMT_READ1(NXT_A, NXT_B, Sn, 1)                       \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 4) GEMT_SB();                                     \
+        if (nxt && !(GEMT_EXP & 8)) GEMT_READ1(NXT_A, NXT_B, Sn, 2)                       \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 5) GEMT_SB();                                     \
+        if (nxt && !(GEMT_EXP & 8)) GEMT_READ1(NXT_A, NXT_B, Sn, 3)                       \
+        GEMT_SB(); GEMT_M(CUR_A, CUR_B, 6) GEMT_M(CUR_A, CUR_B, 7) GEMT_SB();             \
+        /* retire the reads of tile kt+1 here (they landed under the chain), so that hipcc's own conservative lgkmcnt  */ \
+        /* waits in front of the next tile's MFMAs (loop back-edge) find nothing outstanding                            */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0) only; the builtin, so that the compiler's counter model sees it */ \
+    }
+    GEMT_STAGE(0, 0)
+    if (nk > 1) GEMT_STAGE(1, 1)
+    if (nk > 2) GEMT_STAGE(2, 2)
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMT_RAW_BARRIER()
+    GEMT_READ(pa0, pb0, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the loop is entered with nothing outstanding on either path
+    for (int kt = 0; kt < nk; kt += 2) {
+        GEMT_ITER(pa0, pb0, pa1, pb1, kt)
+        GEMT_ITER(pa1, pb1, pa0, pb0, kt + 1)
+    }
+#undef GEMT_ITER
+#undef GEMT_M
+#undef GEMT_READ1
+#undef GEMT_SB
+#undef GEMT_RAW_BARRIER
+#undef GEMT_MFMA
+#undef GEMT_READ
 #undef GEMT_STAGE
 #undef GLDS16
     // epilogue, accumulator map of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg

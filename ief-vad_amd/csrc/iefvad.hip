@@ -439,7 +439,7 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
     const int blocks64 = (a.M / GEMS_BM) * (a.N / GEMS_BN) * nz;
     const bool t256_ok = (a.N % GB2_BN == 0) && (a.K % 16 == 0) && (a.K >= 32);
     const int blocks256 = t256_ok ? (a.M / GB2_BM) * (a.N / GB2_BN) * nz : 0;
-    const bool tiny = blocks64 < 320 && !g_force_no_tiny;      // < 1.25 blocks of 64x64 per CU: the chain, not the chip, bounds it
+    const bool tiny = blocks64 < 320 && a.K % 64 == 0 && !g_force_no_tiny;      // < 1.25 blocks of 64x64 per CU: the chain, not the chip, bounds it
     hipEvent_t e = tm.begin(stage);
     if (tiny) {
         dim3 grid((a.M / GEMT_BM) * (a.N / GEMT_BN), 1, nz);
