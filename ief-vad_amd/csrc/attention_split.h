@@ -71,7 +71,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     float qs = 1.0f, s_inv2 = 1.0f, o_inv = 1.0f;      // fp16x3: operand scale of q / k / v, score and output rescale
     constexpr float kPScale = 8192.0f;                 // P <= 1 -> 2^13
     if constexpr (F16) {
-        const int e = 13 - amax_exponent(amax_read(args.amax_in[mod]));
+        const int e = 13 - amax_exponent(amax_read_chunk(args.amax_in[mod], chunk));
         qs = __builtin_ldexpf(1.0f, e);
         s_inv2 = __builtin_ldexpf(1.0f, -2 * e);
         o_inv = __builtin_ldexpf(1.0f, -13 - e);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
             if constexpr (F16) om = amax_fold(om, ov);
         }
     if constexpr (F16) {      // running max |out| for the out_proj operand scale
-        if (args.amax[mod]) amax_publish(args.amax[mod], wave_max(om), lane);
+        if (args.amax[mod]) amax_store_part(args.amax[mod], chunk, head * 8 + qhalf * 4 + (threadIdx.x >> 6), wave_max(om), lane);
     }
 }
 #undef ATS_SIX

@@ -58,10 +58,28 @@ __device__ __forceinline__ float amax_read(const float* slot) {
     return wave_max(lane < IEF_AMAX_WAYS ? slot[lane * IEF_AMAX_STRIDE] : 0.f);
 }
 
-// floor(log2(amax)) for a finite positive amax; 13 (scale 2^0 below) for zero / non-finite.  Capped at 30: a single huge
-// but finite outlier (|x| > 2^30 -- the reference's fp32 chain overflows to NaN within that element's chunk from ~1e19 on)
-// must not push every other value of the tensor into fp16's subnormals.  With the cap the outlier's own scaled value
-// overflows fp16 instead, which turns ITS chunk into NaN through the attention and leaves the other chunks exact.
+// Activations carry their running maximum PER CHUNK (256 rows): chunks are independent batch rows of the forward (attention
+// never crosses them) and every 128-row GEMM tile lies inside one, so a per-chunk operand scale costs nothing and a huge
+// outlier in one video cannot take precision away from another (round 2; the per-tensor scale of round 1 did).  No atomics:
+// a (tensor, chunk) owns IEF_AMAX_PARTS words, every producing WAVE stores the maximum of what it wrote into a word of its
+// own (row-wise kernels: part = row % 256; GEMM epilogues: part = wave tile index inside the chunk; attention: part =
+// (head, query half, wave)), the words nobody writes stay zero from the micro-batch's memset, and a consumer wave reads all
+// 256 words with one 16-byte load per lane.  (One word per chunk updated with atomicMax was tried first: the workgroups
+// resident at one time all belong to the same few chunks, i.e. to ONE cache line -- LayerNorm 9 -> 59 ms per step.)
+// Weights keep one scale per matrix (the multi-way words above).
+#define IEF_AMAX_PARTS 256
+__device__ __forceinline__ void amax_store_part(float* slot, int chunk, int part, float wave_amax, int lane) {
+    if (lane == 0) slot[(size_t)chunk * IEF_AMAX_PARTS + part] = wave_amax;
+}
+__device__ __forceinline__ float amax_read_chunk(const float* slot, int chunk) {       // call with the whole wave
+    const int lane = threadIdx.x & 63;
+    const f32x4 v = *(const f32x4*)(slot + (size_t)chunk * IEF_AMAX_PARTS + 4 * lane);
+    return wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+}
+
+// floor(log2(amax)) for a finite positive amax; 13 (scale 2^0 below) for zero / non-finite.  Capped at 30: beyond |x| ~ 2^30
+// the scaled value overflows fp16 and the element's chunk becomes NaN (the reference's fp32 chain overflows to NaN within
+// that chunk from ~1e19 on); with per-chunk scales no other chunk is affected either way.
 #define IEF_AMAX_EXP_CAP 30
 __device__ __forceinline__ int amax_exponent(float amax) {
     const unsigned b = __float_as_uint(amax);

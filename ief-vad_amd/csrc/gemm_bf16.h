@@ -246,10 +246,13 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 // instruction.  MF16 selects the accumulator map (16x16 tiles in acc16, else 32x32 tiles in acc).
 // The wave tile is (32 PASSES) rows x 128 columns with origin (wrow0, wcol0) inside the block tile at (m0, n0).
 // `cscale` multiplies the accumulators before the bias (1 except in the fp16x3 path, where it undoes the operand scales);
-// `amax_out` (nullable) receives the running max |value written to C|.
+// `amax_out` (nullable) is the per-chunk running-max slot of C: word (row / 256) receives max |value written|.
 // Result stores of the ring / split kernels.  GB2_NT_STORES=1 marks them non-temporal (global_store ... nt): a launch writes
 // 0.8-4.8 GB that no workgroup of the SAME launch reads again, while the A panels and W planes its co-resident workgroups
 // share must stay in the 4 MB L2 of their XCD.
+#ifndef GB2_EPI_SLEEP
+#define GB2_EPI_SLEEP 0
+#endif
 #ifndef GB2_NT_STORES
 #define GB2_NT_STORES 1      // bf16 ring kernel +3..6 % with fp32 results, split kernels +0..1 % (profiles/r02_gemm_nt_stores.log)
 #endif
@@ -327,9 +330,13 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vmax = amax_fold(vmax, v[e]);
             }
+#if GB2_EPI_SLEEP
+            __builtin_amdgcn_s_sleep(GB2_EPI_SLEEP);      // experiment: spread the stores over the partner's main loop
+#endif
         }
     }
-    if (amax_out) amax_publish(amax_out, wave_max(vmax), lane);
+    if (amax_out)      // a wave tile lies inside one chunk; its word: (32-row band of the chunk, 128-column tile), N <= 4096
+        amax_store_part(amax_out, (m0 + wrow0) / IEF_T, (((m0 + wrow0) % IEF_T) / 32) * (args.N / 128) + (n0 + wcol0) / 128, wave_max(vmax), lane);
 }
 
 // the 2 x 2 wave layout of the 128 x 256 kernels: wave (wr, wc) owns the 64 x 128 tile at (64 wr, 128 wc)
@@ -374,10 +381,14 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     // coincide.  The launch's first 512 workgroups are the two residents of each CU; the second 256 of them (dispatch
     // order is linear in blockIdx -- an observed property used for speed only) wait about half a tile time once, and
     // from then on one resident of a CU stores while the other multiplies.
-    if (args.stagger > 0) {
+    if (args.stagger != 0) {
         const int lin = blockIdx.x + gridDim.x * blockIdx.z;
-        if (lin >= 256 && lin < 512)
-            for (int w = 0; w < args.stagger; ++w) __builtin_amdgcn_s_sleep(127);
+        const int n = args.stagger > 0 ? args.stagger : -args.stagger;
+        // which of the first 512 workgroups share a CU is not documented: > 0 assumes (b, b + 256), < 0 assumes consecutive
+        // workgroups of one XCD, (b, b + 8)
+        const bool late = args.stagger > 0 ? (lin >= 256 && lin < 512) : (lin < 512 && ((lin >> 3) & 1));
+        if (late)
+            for (int w = 0; w < n; ++w) __builtin_amdgcn_s_sleep(127);
     }
 
     // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3

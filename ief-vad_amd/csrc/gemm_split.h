@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
 // F16 = false: three bf16 terms per operand, six products (the production arithmetic).
 // F16 = true (compute = fp16x3, opt-in): two fp16 terms per operand (22 bits), three products h1 g1 + h1 g2 + h2 g1 --
 // half the MFMAs; products good to ~2^-20.4 |a w| worst case (2^-23 typical).  fp16 has a 5-bit exponent, so both operands are scaled by powers of two (exact):
-// A by 2^(13 - floor(log2 amaxA)) from the running max |A| word its producer kernel maintained (P.amaxA), W at
+// A by 2^(13 - floor(log2 amaxA)) from the running max |A| word OF THE TILE'S CHUNK that its producer kernel maintained (P.amaxA), W at
 // iefvad_set_weights by the same rule (P.amaxW); the epilogue multiplies the accumulators by the inverse (cscale).
 // Scaled maxima sit in [2^13, 2^14); elements more than 2^27 below their tensor's maximum fall into fp16's subnormals
 // (absolute error <= 2^-38 of the maximum).  Null amax pointers (tools/gemm_tune_split) mean unscaled operands.
@@ -162,7 +162,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     float ascale = 1.0f, cscale = 1.0f;                // fp16x3: operand scale of A, inverse of both scales
     if constexpr (F16) {
         if (P.amaxA && P.amaxW) {
-            const int ea = 13 - amax_exponent(amax_read(P.amaxA)), ew = 13 - amax_exponent(amax_read(P.amaxW));
+            const int ea = 13 - amax_exponent(amax_read_chunk(P.amaxA, m0 / IEF_T)), ew = 13 - amax_exponent(amax_read(P.amaxW));
             ascale = __builtin_ldexpf(1.0f, ea);
             cscale = __builtin_ldexpf(1.0f, -ea - ew);
         }

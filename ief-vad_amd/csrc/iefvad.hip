@@ -95,8 +95,11 @@ struct iefvad_handle {
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
 };
-static const int kAmaxTensors = 512, kAmaxActBase = 256;   // tensors with a running max: [0, 256) matrices, [256, 512) activations
-static const int kAmaxWords = kAmaxTensors * IEF_AMAX_FLOATS;
+static const int kAmaxActBase = 256;   // running-max slots of the projection matrices (multi-way words); behind them the activations'
+static int amax_act_tensors(int L, int K) { return 2 + 6 * L + 2 * K + 1; }   // inputs, per layer att|x|qkv x 2 modalities, z_0..z_K, h_0..h_{K-1}
+static size_t amax_words(int L, int K, int mb_chunks) {
+    return (size_t)kAmaxActBase * IEF_AMAX_FLOATS + (size_t)amax_act_tensors(L, K) * mb_chunks * IEF_AMAX_PARTS;
+}
 
 // chunks per internal pass: 256 (65,536 rows, 2.8 GB of workspace) in fp32 mode; the bf16 kernels are ~100 us
 // each at that size and gain another 7 % from 4x longer launches (1024 chunks, 11 GB of workspace)
@@ -161,7 +164,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_split_f16_n128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GS_LDS_BYTES_OF(2));
-    if (e == hipSuccess && cfg->compute == IEFVAD_COMPUTE_FP16X3) e = hipMalloc((void**)&h->amax_dev, kAmaxWords * sizeof(float));
+    if (e == hipSuccess && cfg->compute == IEFVAD_COMPUTE_FP16X3) e = hipMalloc((void**)&h->amax_dev, amax_words(cfg->num_layers, cfg->num_steps, micro_batch(h)) * sizeof(float));
     if (e != hipSuccess) {
         delete h;
         return fail("iefvad_create: %s", hipGetErrorString(e));
@@ -648,17 +651,20 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         const bool splitmb = (c.compute == IEFVAD_COMPUTE_BF16X6 || c.compute == IEFVAD_COMPUTE_FP16X3) &&
                              split_eligible(rows, IEF_D, IEF_D, 1);
         const bool f16mb = splitmb && c.compute == IEFVAD_COMPUTE_FP16X3;
+        // activation tensor t owns IEF_AMAX_PARTS words per chunk of the micro-batch
         float* am = h->amax_dev ? h->amax_dev + kAmaxActBase * IEF_AMAX_FLOATS : nullptr;
-        auto am_in = [&](int m) { return f16mb ? am + IEF_AMAX_FLOATS * m : nullptr; };
-        auto am_att = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + m) : nullptr; };
-        auto am_x = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + 2 + m) : nullptr; };
-        auto am_qkv = [&](int l, int m) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * l + 4 + m) : nullptr; };
-        auto am_z = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * L + k) : nullptr; };
-        auto am_h = [&](int k) { return f16mb ? am + IEF_AMAX_FLOATS * (2 + 6 * L + (K + 1) + k) : nullptr; };
+        const size_t mbs = (size_t)mb * IEF_AMAX_PARTS;
+        auto am_t = [&](int t) { return f16mb ? am + mbs * t : nullptr; };
+        auto am_in = [&](int m) { return am_t(m); };
+        auto am_att = [&](int l, int m) { return am_t(2 + 6 * l + m); };
+        auto am_x = [&](int l, int m) { return am_t(2 + 6 * l + 2 + m); };
+        auto am_qkv = [&](int l, int m) { return am_t(2 + 6 * l + 4 + m); };
+        auto am_z = [&](int k) { return am_t(2 + 6 * L + k); };
+        auto am_h = [&](int k) { return am_t(2 + 6 * L + (K + 1) + k); };
         if (f16mb) {
-            HIP_TRY(hipMemsetAsync(am, 0, (kAmaxTensors - kAmaxActBase) * IEF_AMAX_FLOATS * sizeof(float), stream));
+            HIP_TRY(hipMemsetAsync(am, 0, (size_t)amax_act_tensors(L, K) * mbs * sizeof(float), stream));
             hipEvent_t e = tm.begin(ST_CAST);
-            hipLaunchKernelGGL(iefvad_amax_kernel, dim3(2048, 2), dim3(256), 0, stream, cur[0], cur[1], am_in(0), am_in(1), R * D);
+            hipLaunchKernelGGL(iefvad_amax_chunk_kernel, dim3(nb, 2), dim3(256), 0, stream, cur[0], cur[1], am_in(0), am_in(1));
             tm.end(e);
             HIP_TRY(hipGetLastError());
         }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) m = amax_fold(m, v[j][e]);
-        amax_publish(a.amax[mod], wave_max(m), lane);
+        amax_store_part(a.amax[mod], row / IEF_T, row % IEF_T, wave_max(m), lane);
     }
 }
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
         *(f32x4*)(a.z + o) = z;
         if (a.zb) *(bf16x4_t*)(a.zb + o) = to_bf16x4(z);
     }
-    if (a.z_amax) amax_publish(a.z_amax, wave_max(zm), lane);
+    if (a.z_amax) amax_store_part(a.z_amax, row / IEF_T, row % IEF_T, wave_max(zm), lane);
     if (a.n_i_mean || a.n_e_mean) {
         si = wave_sum(si) * (1.0f / IEF_D);
         se = wave_sum(se) * (1.0f / IEF_D);
@@ -191,4 +191,21 @@ __global__ __launch_bounds__(256) void iefvad_amax_kernel(const float* in0, cons
         for (int e = 0; e < 4; ++e) m = amax_fold(m, v[e]);
     }
     amax_publish(out, wave_max(m), threadIdx.x & 63);
+}
+
+// ---- per-chunk max |x| of the raw inputs (fp16x3 mode): one workgroup per (chunk, modality), no atomics
+__global__ __launch_bounds__(256) void iefvad_amax_chunk_kernel(const float* in0, const float* in1, float* out0, float* out1) {
+    __shared__ float part[4];
+    const float* in = (blockIdx.y ? in1 : in0) + (size_t)blockIdx.x * IEF_T * IEF_D;
+    float* out = blockIdx.y ? out1 : out0;
+    float m = 0.f;
+    for (int i = threadIdx.x * 4; i < IEF_T * IEF_D; i += 256 * 4) {
+        const f32x4 v = *(const f32x4*)(in + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = amax_fold(m, v[e]);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * IEF_AMAX_PARTS] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
