@@ -4,6 +4,7 @@
 // iefvad_amd.synth.state_dict_keys(L, K), 3 floats of padding, then img [B,256,768], then ev [B,256,768].
 // Writes B*256 fp32 logits.  Exit code 0 on success; any ABI error prints iefvad_last_error().
 #include <hip/hip_runtime_api.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -91,7 +92,33 @@ int main(int argc, char** argv) {
         fprintf(stderr, "small workspace was not refused\n");
         return 4;
     }
-    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches\n", B, L, K, st.total_ms, st.gemm_launches);
+    // the score gather with no torch in the process: librccl is bound from the system ROCm by dlopen; a
+    // one-rank communicator exercises id -> init -> count -> all-gather (equal counts) -> the unequal-count bookkeeping
+    {
+        unsigned char ident[IEFVAD_COMM_ID_BYTES];
+        ABICK(iefvad_comm_unique_id(ident));
+        iefvad_comm* comm = nullptr;
+        ABICK(iefvad_comm_create(ident, 1, 0, &comm));
+        if (iefvad_comm_nranks(comm) != 1) { fprintf(stderr, "comm_nranks != 1\n"); return 5; }
+        float* gathered = nullptr;
+        HIPCK(hipMalloc((void**)&gathered, (size_t)B * T * 4));
+        HIPCK(hipMemsetAsync(gathered, 0xff, (size_t)B * T * 4, stream));
+        ABICK(iefvad_gather_scores(comm, logits, (size_t)B * T, nullptr, gathered, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        std::vector<float> hg((size_t)B * T);
+        HIPCK(hipMemcpy(hg.data(), gathered, hg.size() * 4, hipMemcpyDeviceToHost));
+        if (memcmp(hg.data(), hl.data(), hg.size() * 4) != 0) { fprintf(stderr, "gathered scores differ from the local ones\n"); return 5; }
+        const int64_t counts[1] = {(int64_t)T};          // only the first chunk's scores
+        HIPCK(hipMemsetAsync(gathered, 0xff, (size_t)B * T * 4, stream));
+        ABICK(iefvad_gather_scores(comm, logits, 0, counts, gathered, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        HIPCK(hipMemcpy(hg.data(), gathered, T * 4, hipMemcpyDeviceToHost));
+        if (memcmp(hg.data(), hl.data(), T * 4) != 0) { fprintf(stderr, "counted gather differs\n"); return 5; }
+        if (iefvad_gather_scores(nullptr, logits, 1, nullptr, gathered, stream) == 0) { fprintf(stderr, "null comm accepted\n"); return 5; }
+        iefvad_comm_destroy(comm);
+        (void)hipFree(gathered);
+    }
+    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, gather through librccl OK\n", B, L, K, st.total_ms, st.gemm_launches);
     iefvad_destroy(h);
     (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);
     return 0;
