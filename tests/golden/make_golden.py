@@ -75,8 +75,14 @@ def case_inputs(in_seed, B, dtype, edit):
     return img, ev
 
 
-def gen_forward_cases():
-    for name, wseed, iseed, B, L, K, lam, noise, nu, dt, edit in CASES:
+# A batch large enough for the split kernels of the bf16x6 / fp16x3 arithmetics (>= 43 chunks): every chunk's logits and
+# weight means, the 768-d outputs of three chunks only (keeps the fixture under 1 MB).
+BIG_CASE = ("b48_k10_student8", 17, 29, 48, 2, 10, 0.5, "StudentT", 8, "f32", "tail")
+BIG_CASE_CHUNKS = [0, 17, 47]
+
+
+def gen_forward_cases(cases=None, chunk_subset=None):
+    for name, wseed, iseed, B, L, K, lam, noise, nu, dt, edit in (cases or CASES):
         model = build_reference(wseed, L, K, lam, noise, nu)
         img, ev = case_inputs(iseed, B, dt, edit)
         with torch.no_grad():
@@ -88,6 +94,10 @@ def gen_forward_cases():
                  "noise": np.array(noise), "in_dtype": np.array(dt), "edit": np.array(str(edit))}
         for k in BIG_KEYS:
             store[k] = out[k].numpy()[:, ROW_SUBSET, :]
+            if chunk_subset is not None:
+                store[k] = store[k][chunk_subset]
+        if chunk_subset is not None:
+            store["chunks"] = np.array(chunk_subset)
         path = os.path.join(HERE, f"fwd_{name}.npz")
         np.savez_compressed(path, **store)
         print("wrote", path, os.path.getsize(path) // 1024, "KiB")
@@ -224,11 +234,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         gen_init_checksums()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b48":
+        gen_forward_cases([BIG_CASE], BIG_CASE_CHUNKS)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gen_sweep_case()
         sys.exit(0)
     torch.manual_seed(0)
     gen_forward_cases()
+    gen_forward_cases([BIG_CASE], BIG_CASE_CHUNKS)
     gen_harness_case()
     gen_init_checksums()
     gen_sweep_case()

@@ -49,7 +49,7 @@ def test_bf16_gemm_kernel_matches_fp64_of_rounded_operands():
         assert err < 2e-4, (M, N, K, err)
 
 
-@pytest.mark.parametrize("name", H.golden_cases())
+@pytest.mark.parametrize("name", H.golden_cases() + H.golden_cases(big=True))
 def test_bf16_forward_within_bf16_noise_of_reference(name):
     g, cfg, sd, img, ev = H.load_case(name)
     model = make_model(cfg["L"], cfg["K"], cfg["lam"], cfg["noise"], cfg["nu"], sd)

@@ -223,3 +223,21 @@ def test_input_scale_3000_is_ill_conditioned_in_every_arithmetic(compute):
         r32 = orc.forward(sd, ti, te, cfg)
         o_err = (r32["fused"].double() - r64["fused"]).abs().amax(-1).numpy()
         assert (o_err > 2 * H.TOL_BIG).any() and bad.any()
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16x6", "fp16x3"])
+@pytest.mark.parametrize("name", H.golden_cases(big=True))
+def test_split_sized_batch_against_the_reference_fixture(name, compute):
+    """The split kernels (B >= 43 chunks) compared DIRECTLY with outputs the reference model itself produced at B = 48
+    (tests/golden/fwd_b48_*.npz, written by tests/golden/make_golden.py from /root/reference/model/imf_vad.py), not only
+    with the oracle: every chunk's logits / sigmoid / weight means, the 768-d outputs of three chunks, fp32 gates."""
+    g, cfg, sd, img, ev = H.load_case(name)
+    args = argparse.Namespace(visual_layers=cfg["L"], visual_head=8, num_refinement_steps=cfg["K"], lambda_ref=cfg["lam"],
+                              noise_model=cfg["noise"], nu=cfg["nu"])
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, cfg["L"], 8, 10, 10, "cuda", args, compute=compute)
+    m.load_state_dict(sd)
+    got = run(m.to("cuda:0").eval(), img, ev)
+    errs = H.compare_outputs(got, g)
+    assert np.abs(got["w_i"].mean(-1) - g["w_i_mean"]).max() < 2e-6
+    assert np.abs(got["w_e"].mean(-1) - g["w_e_mean"]).max() < 2e-6
+    print(name, compute, errs)

@@ -20,6 +20,19 @@ def test_oracle_matches_reference_outputs(name):
     print(name, errs)
 
 
+@pytest.mark.parametrize("name", H.golden_cases(big=True))
+def test_oracle_matches_reference_outputs_at_a_split_sized_batch(name):
+    """B = 48 (large enough for the split kernels of the bf16x6 / fp16x3 arithmetics): all chunks' logits and weight
+    means, the 768-d outputs of three chunks, against the reference's own outputs."""
+    g, cfg, sd, img, ev = H.load_case(name)
+    torch.set_num_threads(8)
+    out = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), H.oracle_cfg(cfg))
+    out = {k: v.numpy() for k, v in out.items()}
+    H.compare_outputs(out, g)
+    assert np.abs(out["w_i"].mean(-1) - g["w_i_mean"]).max() < 2e-6
+    assert np.abs(out["w_e"].mean(-1) - g["w_e_mean"]).max() < 2e-6
+
+
 def test_oracle_fp64_noise_floor():
     """fp32 vs fp64 evaluation of the same restatement: the noise floor the fp32 gates sit on."""
     g, cfg, sd, img, ev = H.load_case("base_k10_student8")
