@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
     }
     __syncthreads();
 
+    // V is fetched NOW, into registers (12 x 16 B per thread), and written to LDS after the softmax: its load latency runs
+    // under the 48 MFMAs of K Q^T and the softmax instead of standing between two barriers
+    bf16x8 vstage[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int c = t + 256 * j;
+        const int row = c / 12, ch = c - row * 12;
+        vstage[j] = *(const bf16x8*)(qkv + (size_t)row * (3 * IEF_D) + 2 * IEF_D + ch * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     f32x16 st[8];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
     for (int j = 0; j < 12; ++j) {
         const int c = t + 256 * j;
         const int row = c / 12, ch = c - row * 12;
-        *(bf16x8*)(kv + row * ATTB_VROW + ch * 8) = *(const bf16x8*)(qkv + (size_t)row * (3 * IEF_D) + 2 * IEF_D + ch * 8);
+        *(bf16x8*)(kv + row * ATTB_VROW + ch * 8) = vstage[j];
     }
     __syncthreads();
 

@@ -92,7 +92,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs a
 
 #pragma unroll
     for (int ti = 0; ti < 8; ++ti) {
-        if (ti + 1 < 8) { ATT_LOAD(ti + 1) }
+        if (ti + 1 < 8) {
+            ATT_LOAD(ti + 1)
+            // keep the loads HERE: left alone, hipcc sinks them behind the tile's 96 MFMAs (to save 24 registers) and the
+            // wave then waits out the whole load latency in front of the LDS write, every tile
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const float* T = kv + (ti & 1) * ATT_TILE;
         if (ti < 4) {
             // S^T[key][query] = sum_d K[key][d] Q[query][d] for the two 32-key sub-tiles of this tile
