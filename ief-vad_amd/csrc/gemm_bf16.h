@@ -284,6 +284,52 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
     if (epi == EPI_HEADS && ncol >= IEF_D) { C32 = P.C2; nn = ncol - IEF_D; }
     if (epi == EPI_QKV && ncol < args.qcols) scale = f32x4{alpha, alpha, alpha, alpha};
     float vmax = 0.f;
+    // bf16-only results (in_proj q|k|v and the refinement's ReLU output in the bf16 mode): a lane takes EIGHT columns of a row,
+    // so that a store is 16 bytes per lane like the fp32 ones (half the store instructions of the 8-byte form)
+    const bool wide16 = C16 && !C32 && !has_resid && !amax_out && (epi == EPI_BIAS || epi == EPI_QKV || epi == EPI_BIAS_RELU);
+    if (wide16) {
+        const int rq4 = lane >> 4, c8 = lane & 15;
+        const int ncol8 = n0 + wcol0 + 8 * c8;
+        const f32x4 b0 = *(const f32x4*)(P.bias + ncol8), b1 = *(const f32x4*)(P.bias + ncol8 + 4);
+        const float sc = (epi == EPI_QKV && ncol8 < args.qcols) ? alpha : 1.f;      // qcols is a multiple of 8
+#pragma unroll
+        for (int a = 0; a < PASSES; ++a) {
+            if constexpr (MF16) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            E[(x * 16 + 4 * q16 + r) * GB2_EPI_LD + b * 16 + r16] = acc16[2 * a + x][b][r];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        E[((r & 3) + 8 * (r >> 2) + 4 * h) * GB2_EPI_LD + b * 32 + i] = acc[a][b][r];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = rq4 + 4 * u;
+                f32x4 v0 = *(const f32x4*)(E + row * GB2_EPI_LD + 8 * c8);
+                f32x4 v1 = *(const f32x4*)(E + row * GB2_EPI_LD + 8 * c8 + 4);
+                v0 = v0 * cscale + b0;
+                v1 = v1 * cscale + b1;
+                if (epi == EPI_QKV) { v0 = v0 * sc; v1 = v1 * sc; }
+                bf16x8 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v0[e], x1 = v1[e];
+                    if (epi == EPI_BIAS_RELU) { x0 = x0 < 0.f ? 0.f : x0; x1 = x1 < 0.f ? 0.f : x1; }
+                    w[e] = (bf16_t)x0;
+                    w[4 + e] = (bf16_t)x1;
+                }
+                GB2_STORE((bf16x8*)(C16 + (size_t)(m0 + wrow0 + a * 32 + row) * ldc + ncol8), w);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < PASSES; ++a) {
         const int mrow = m0 + wrow0 + a * 32 + rq;
