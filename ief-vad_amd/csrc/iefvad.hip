@@ -826,6 +826,7 @@ struct GraphCache {
     float* big_buf = nullptr;    // the seven [B*T, D] outputs (allocated on the first call that asks for one)
     int max_chunks = 0;
     unsigned long long clock = 0;
+    bool disabled = false;       // capture or instantiation failed once: every later call launches directly
     std::vector<GraphEntry> entries;
 };
 
@@ -888,8 +889,14 @@ static int forward_graphed(iefvad_handle* h, const void* img, const void* ev, in
         iefvad_outputs so;
         float** sf = (float**)&so;
         for (int i = 0; i < 10; ++i) sf[i] = of[i] ? s_out[i] : nullptr;
+        // The graph is an optimisation: if capture or instantiation is refused (a capture already active on this thread, an
+        // exhausted graph pool ...), remember it and let the caller's direct path run instead.
         Timer tm;
-        HIP_TRY(hipStreamBeginCapture(gc.cap_stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(gc.cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            gc.disabled = true;
+            return -1;
+        }
         const int rc = forward_impl(h, s_img, s_ev, in_dtype, B, workspace, workspace_bytes, &so, gc.cap_stream, tm);
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(gc.cap_stream, &graph);      // always end the capture, also after a failed launch
@@ -897,11 +904,14 @@ static int forward_graphed(iefvad_handle* h, const void* img, const void* ev, in
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
         }
-        if (ce != hipSuccess || !graph) return fail("iefvad_forward: hipStreamEndCapture: %s", hipGetErrorString(ce));
         hipGraphExec_t exec = nullptr;
-        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) return fail("iefvad_forward: hipGraphInstantiate: %s", hipGetErrorString(ie));
+        hipError_t ie = (ce == hipSuccess && graph) ? hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) : hipErrorUnknown;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) {
+            (void)hipGetLastError();
+            gc.disabled = true;
+            return -1;
+        }
         if ((int)gc.entries.size() >= kGraphMaxEntries) {                      // evict the least recently used graph
             size_t lru = 0;
             for (size_t i = 1; i < gc.entries.size(); ++i)
@@ -927,7 +937,12 @@ extern "C" int iefvad_forward(iefvad_handle* h, const void* img, const void* ev,
     if (h && out && img && ev && h->weights_set && B > 0 && B <= graph_limit(h) && workspace &&
         workspace_bytes >= iefvad_workspace_bytes(h, B) && !(((uintptr_t)workspace | (uintptr_t)img | (uintptr_t)ev) & 15) &&
         (in_dtype == IEFVAD_IN_F32 || in_dtype == IEFVAD_IN_F16 || in_dtype == IEFVAD_IN_BF16))
-        return forward_graphed(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream);
+    {
+        if (!(h->graphs && h->graphs->disabled)) {
+            const int rc = forward_graphed(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream);
+            if (rc >= 0) return rc;            // -1: graphs unavailable, fall through to direct launches
+        }
+    }
     Timer tm;      // everything else, and every invalid argument (reported by forward_impl), takes the direct path
     return forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream, tm);
 }
