@@ -31,6 +31,9 @@ The JSON line also carries
                 modes `mfma_pipe_util` is the EXECUTED-product rate / peak (6 bf16 products per algorithmic one).
   cpu_baseline  the CPU oracle (oracle/iefvad_oracle.py, torch CPU ops on the host cores) on a bounded sample of the
                 same workload, rank 0 at N=1 only.  A reported baseline, not the target.
+  xd_eval, shang_msad_eval   BASELINE configs 3 and 5 (XD-Violence-sized; ShanghaiTech + MSAD sized with K = 5), bf16 projections
+                with fp32 state, packed evaluation loop: snippets/s, AUC / AP, and their distance from the fp32 CPU oracle on a
+                bounded prefix of the list.
   ucf_eval      BASELINE config 2 (UCF-Crime-sized synthetic set, 290 videos, ~69.5 k snippets) through harness.test:
                 the reference's per-video call pattern and the cross-video batched pattern, snippets/s wall clock
                 including H2D, |dAUC| against the CPU oracle on a bounded sample, and the oracle's own rate.
@@ -80,7 +83,7 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-modes", action="store_true",
                    help="skip the side passes (f32_mfma_mode, bf16_mode, fp16x3_mode, weak_scaling)")
-    p.add_argument("--no-ucf-eval", action="store_true")
+    p.add_argument("--no-ucf-eval", action="store_true", help="skip the dataset-shaped blocks (ucf_eval, xd_eval, shang_msad_eval)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-oracle sample")
     p.add_argument("--plumbing-only", action="store_true",
                    help="launcher self-test for machines without a GPU (tests/test_bench_launcher_cpu.py): NO forward runs; "
@@ -295,6 +298,67 @@ def ucf_eval(sd, margs, dev, a):
     return out
 
 
+def dataset_eval(tag, dataset, nvid, total_target, seed, wseed, K, compute, dev, a, lo=16, hi=8000, batch_chunks=256,
+                 normal_keys=("Normal",)):
+    """One of BASELINE's dataset-shaped configs (3: XD-Violence-sized, bf16; 5: ShanghaiTech + MSAD sized, K = 5, bf16) through
+    the evaluation loop: synthetic features of the set's size held in host memory, chunks packed across videos, wall clock
+    including the H2D copies; AUC / AP / Ano-AUC against the fp32 CPU oracle on a bounded prefix of the same list."""
+    import numpy as np
+    import torch
+    from iefvad_amd import harness, synth
+    from oracle import iefvad_oracle as orc
+    lengths = synth.lognormal_lengths(seed, nvid, total_target, lo=lo, hi=hi)
+    keys = harness.CLASS_KEYS[dataset]
+    classes = [keys[i % len(keys)] for i in range(nvid)]
+    total = int(lengths.sum())
+    gt = synth.make_gt(seed, total)
+    items = []
+    for i, n in enumerate(lengths):
+        img, ev = synth.make_video(seed, i, int(n))
+        ci, _ = harness.process_split(img, T)
+        ce, _ = harness.process_split(ev, T)
+        items.append((torch.from_numpy(ci).unsqueeze(0), torch.from_numpy(ce).unsqueeze(0), (classes[i],), torch.tensor([int(n)])))
+    margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K, lambda_ref=0.5, noise_model="StudentT", nu=8)
+    sd = synth.make_state_dict(wseed, D, L, K)
+    model = make_model(sd, margs, dev, a, compute, outputs="scores")
+    harness.score_loader(model, items[:8], T, dev, dataset, batch_chunks=batch_chunks)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scores, cls, _, _ = harness.score_loader(model, items, T, dev, dataset, batch_chunks=batch_chunks)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = harness.evaluate_scores(scores, cls, gt, dataset, verbose=False, normal_keys=normal_keys)
+    out = {"workload": f"{tag}: synthetic {dataset}-shaped test set, {nvid} videos, {total} snippets, K={K}, projections={compute}, "
+                       f"chunks of consecutive videos packed into forwards of >= {batch_chunks}",
+           "videos": nvid, "snippets": total, "compute": compute, "snippets_per_s": total / dt, "seconds": dt,
+           "auc": res["roc"], "ap": res["ap"], "ano_auc": res["ano_auc"]}
+    del model
+    # fp32 CPU oracle on a prefix of the list that covers every class key (the metric tail needs them all), bounded in time
+    torch.set_num_threads(host_cpu_share())
+    oracle = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K, nu=8))
+    t0 = time.perf_counter()
+    cpu_scores = []
+    step = 8
+    for lo_i in range(0, nvid, step):
+        sc, _, _, _ = harness.score_loader(oracle, items[lo_i:lo_i + step], T, "cpu", dataset, batch_chunks=8)
+        cpu_scores += sc
+        if time.perf_counter() - t0 > a.cpu_seconds and len(cpu_scores) >= 4 * len(keys):
+            break
+    t_cpu = time.perf_counter() - t0
+    nv = len(cpu_scores)
+    nsub = int(sum(len(x) for x in cpu_scores))
+    gt_sub = gt[:16 * nsub]
+    r_cpu = harness.evaluate_scores(cpu_scores, classes[:nv], gt_sub, dataset, verbose=False, normal_keys=normal_keys)
+    r_gpu = harness.evaluate_scores(scores[:nv], classes[:nv], gt_sub, dataset, verbose=False, normal_keys=normal_keys)
+    out["vs_fp32_cpu_oracle_on_sample"] = {
+        "videos": nv, "snippets": nsub, "oracle_snippets_per_s": nsub / t_cpu, "cores": torch.get_num_threads(),
+        "max_abs_score_diff": float(np.abs(np.concatenate(scores[:nv]) - np.concatenate(cpu_scores)).max()),
+        "abs_auc_diff": abs(r_gpu["roc"] - r_cpu["roc"]), "abs_ap_diff": abs(r_gpu["ap"] - r_cpu["ap"]),
+        "abs_ano_auc_diff": abs(r_gpu["ano_auc"] - r_cpu["ano_auc"])}
+    out["x_cpu_oracle"] = out["snippets_per_s"] / (nsub / t_cpu)
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -477,6 +541,11 @@ def main():
             model = None
             torch.cuda.empty_cache()
             line["ucf_eval"] = ucf_eval(sd, margs, dev, a)
+            # BASELINE configs 3 and 5 (bf16 projections, fp32 state), bounded: driver-side records of what tests/test_gpu_bf16.py gates
+            line["xd_eval"] = dataset_eval("BASELINE config 3", "xd", 753, 145000, 2, 17, 10, "bf16", dev, a, batch_chunks=512,
+                                           normal_keys=("normal",))
+            line["shang_msad_eval"] = dataset_eval("BASELINE config 5", "msad", 438, 17732, 5, 19, 5, "bf16", dev, a, lo=4, hi=400,
+                                                   batch_chunks=128)
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)

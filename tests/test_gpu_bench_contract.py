@@ -45,3 +45,9 @@ def test_default_line_structure_and_consistency():
         assert u[k]["max_abs_score_diff_vs_oracle_on_sample"] <= 2e-6       # fp32 gate on sigmoid(logit)
         assert u[k]["abs_auc_diff_vs_oracle_on_sample"] <= 1e-4             # north star: AUC within 1e-4
     assert u["per_video_f32"]["x_cpu_oracle"] >= 10                          # north star: >= 10x the reference CPU path
+    for key, nvid in (("xd_eval", 753), ("shang_msad_eval", 438)):           # BASELINE configs 3 and 5: bf16 projections
+        e = d[key]
+        assert e["videos"] == nvid and e["compute"] == "bf16" and e["snippets_per_s"] > 0
+        c = e["vs_fp32_cpu_oracle_on_sample"]
+        assert c["max_abs_score_diff"] <= 5e-3                               # bf16 gate on sigmoid(logit), tests/test_gpu_bf16.py
+        assert c["abs_auc_diff"] <= 1e-4 and c["abs_ap_diff"] <= 1e-4
