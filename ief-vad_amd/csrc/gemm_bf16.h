@@ -403,8 +403,18 @@ __device__ __forceinline__ void gemm_t256_epilogue(const GemmBArgs& args, const 
 // G[(row>>2)&3], G = {2,0,1,3}, which makes the (row, q) access pattern of the 16x16 fragment conflict-free.
 enum { T256_BF16_32 = 0, T256_F32 = 1, T256_BF16_16 = 2, T256_BF16_16P = 3 };   // 3 = 2 with the pinned issue order below
 
-template <int MODE>
+// BM = 128: 4 waves (2 x 2 of 64 x 128), two workgroups per CU.  BM = 256 (MODE 3 only): 8 waves (4 x 2 of 64 x 128), ONE workgroup
+// per CU, 256 x 256 block tile: a k-tile stages 32 KB for twice the MFMAs of two 128 x 256 tiles' 48 KB -- the bf16 main
+// loop is bound by what a CU can take in through LDS-DMA (~46-68 GB/s; 47 B/clk at the full MFMA rate with 128 x 256 tiles).
+template <int MODE, int BM = GB2_BM>
 __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* smem) {
+    constexpr int NTHR = 2 * BM;                        // 256 or 512 threads
+    constexpr int RPJ = NTHR / 4;                       // rows one staging instruction of the whole workgroup covers (64 / 128)
+    constexpr int NJA = BM / RPJ, NJW = GB2_BN / RPJ;   // staging instructions per wave and k-tile: A (2), W (4 / 2)
+    constexpr int SLOT = (BM + GB2_BN) * 16;            // 4-byte units per ring slot
+#ifdef GB2_CLOCK_DIAG
+    const unsigned long long dg_entry = __builtin_amdgcn_s_memtime();
+#endif
     constexpr bool F32 = (MODE == T256_F32);
     constexpr bool MF16 = (MODE == T256_BF16_16 || MODE == T256_BF16_16P);
     constexpr bool PIPE = (MODE == T256_BF16_16P);
@@ -414,7 +424,7 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     const int ntn = args.N / GB2_BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int m0 = tm * GB2_BM, n0 = tn * GB2_BN;
+    const int m0 = tm * BM, n0 = tn * GB2_BN;
     const int K = args.K, lda = args.lda;
 
     const int t = threadIdx.x;
@@ -437,12 +447,12 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
             for (int w = 0; w < n; ++w) __builtin_amdgcn_s_sleep(127);
     }
 
-    // staging: thread t moves chunk (row = (t>>2) + 64 j, slot chunk = t&3); A: j = 0..1, W: j = 0..3
+    // staging: thread t moves chunk (row = (t>>2) + RPJ j, slot chunk = t&3); A: j < NJA, W: j < NJW
     const int srow = t >> 2, sch = t & 3;
     auto swz = [](int row) { const int x = (row >> 2) & 3; return MF16 ? ((0xD2 >> (2 * x)) & 3) : x; };
     const int ssw = swz(srow);                          // rows srow + 64 j share it
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * EB), 0,
-                                                       (int)((GB2_BM - 1) * lda + K) * EB, 0x00020000);
+                                                       (int)((BM - 1) * lda + K) * EB, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * EB), 0,
                                                        (int)((GB2_BN - 1) * K + K) * EB, 0x00020000);
     const int voA = srow * lda * EB + ((sch ^ ssw) << 4);
@@ -453,10 +463,10 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 #define GB2_STAGE(tile, slotbase)                                                                     \
     {                                                                                                 \
         float* Ad = smem + (slotbase) + wbase;                                                        \
-        float* Wd = Ad + GB2_BM * 16;                                                                 \
+        float* Wd = Ad + BM * 16;                                                                     \
         const int kk = (tile) * BKE;                                                               \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) GLDS16(rsA, voA, (64 * j * lda + kk) * EB, Ad + 64 * j * 16); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(rsW, voW, (64 * j * K + kk) * EB, Wd + 64 * j * 16);   \
+        _Pragma("unroll") for (int j = 0; j < NJA; ++j) GLDS16(rsA, voA, (RPJ * j * lda + kk) * EB, Ad + RPJ * j * 16); \
+        _Pragma("unroll") for (int j = 0; j < NJW; ++j) GLDS16(rsW, voW, (RPJ * j * K + kk) * EB, Wd + RPJ * j * 16);   \
     }
 
     const int fsw = (i >> 2) & 3;
@@ -464,12 +474,12 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 #pragma unroll
     for (int x = 0; x < 2; ++x) aoff[x] = (wr * 64 + x * 32 + i) * 16;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) boff[x] = GB2_BM * 16 + (wc * 128 + x * 32 + i) * 16;
+    for (int x = 0; x < 4; ++x) boff[x] = BM * 16 + (wc * 128 + x * 32 + i) * 16;
     // 16x16x32 fragments: lane (r16, q16) reads row (16 x + r16), chunk q16 (swizzled) of the A / W image
     const int r16 = lane & 15, q16 = lane >> 4;
     const int f16 = (q16 ^ swz(r16)) << 2;              // rows 16 x + r16 share (row>>2)&3 with r16
     const int a16 = (wr * 64 + r16) * 16 + f16;
-    const int b16 = GB2_BM * 16 + (wc * 128 + r16) * 16 + f16;
+    const int b16 = BM * 16 + (wc * 128 + r16) * 16 + f16;
 
     f32x16 acc[2][4];
     f32x4 acc16[4][8];
@@ -530,10 +540,10 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
 #define GB2_DMA1(n_, tile, slotbase)                                                                       \
     {                                                                                                      \
         float* Ad = smem + (slotbase) + wbase;                                                             \
-        float* Wd = Ad + GB2_BM * 16;                                                                      \
+        float* Wd = Ad + BM * 16;                                                                          \
         const int kk = (tile) * BKE;                                                                       \
-        if ((n_) < 2) GLDS16(rsA, voA, (64 * (n_) * lda + kk) * EB, Ad + 64 * (n_) * 16);                  \
-        else GLDS16(rsW, voW, (64 * ((n_) - 2) * K + kk) * EB, Wd + 64 * ((n_) - 2) * 16);                 \
+        if ((n_) < NJA) GLDS16(rsA, voA, (RPJ * (n_) * lda + kk) * EB, Ad + RPJ * (n_) * 16);              \
+        else if ((n_) < NJA + NJW) GLDS16(rsW, voW, (RPJ * ((n_) - NJA) * K + kk) * EB, Wd + RPJ * ((n_) - NJA) * 16); \
     }
 #define GB2_PSTEP(b_, DMA_)                                                                                \
     {                                                                                                      \
@@ -561,22 +571,32 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     }
 
     const int nk = K / BKE;          // >= 2
-    int s0 = 0, s1 = GB2_SLOT, s2 = 2 * GB2_SLOT;     // slot of tile kt, kt+1, kt+2 (float offsets), rotated each tile
+    int s0 = 0, s1 = SLOT, s2 = 2 * SLOT;     // slot of tile kt, kt+1, kt+2 (float offsets), rotated each tile
     GB2_STAGE(0, s0)
     GB2_STAGE(1, s1)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (NJA + NJW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     GB2_BARRIER();
 #ifdef GB2_CLOCK_DIAG
     const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_last = dg_c0, dg_acc[3] = {0, 0, 0};   // cycles in: k-tile body | vmcnt + lgkmcnt wait | barrier
+#define GB2_DIAG_STAMP(i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); dg_acc[i] += now - dg_last; dg_last = now; }
+#else
+#define GB2_DIAG_STAMP(i)
 #endif
     int kt = 0;
     if constexpr (PIPE) {
         for (; kt + 2 < nk; ++kt) {
             const int dma_tile = kt + 2, dma_slot = s2;   // s2 held tile kt-1: every wave passed the barrier after reading it
             GB2_COMPUTE_PIPE(s0, true)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own DMAs of tile kt+1 landed; tile kt+2's six stay in flight
+            GB2_DIAG_STAMP(0)
+            // own DMAs of tile kt+1 landed; the NJA + NJW of tile kt+2 stay in flight
+            if constexpr (NJA + NJW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GB2_DIAG_STAMP(1)
             GB2_BARRIER();
+            GB2_DIAG_STAMP(2)
             const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
         }
         {
@@ -608,8 +628,12 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
         unsigned long long* dg = (unsigned long long*)P.C2 + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
         dg[0] = __builtin_amdgcn_s_memtime() - dg_c0;
         dg[1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+        unsigned long long* dx = (unsigned long long*)P.C2 + 2 * gridDim.x * gridDim.z + 3 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dx[0] = dg_acc[0]; dx[1] = dg_acc[1]; dx[2] = dg_acc[2];
     }
+    const unsigned long long dg_loop_end = __builtin_amdgcn_s_memtime();
 #endif
+#undef GB2_DIAG_STAMP
 #undef GB2_COMPUTE_PIPE
 #undef GB2_PSTEP
 #undef GB2_DMA1
@@ -620,12 +644,27 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
     GB2_BARRIER();                     // every wave is done with the ring: reuse it for the epilogue
 
     gemm_t256_epilogue<MF16>(args, P, smem, m0, n0, acc, acc16);
+#ifdef GB2_CLOCK_DIAG
+    if (threadIdx.x == 0 && P.C2) {
+        unsigned long long* dy = (unsigned long long*)P.C2 + 5 * gridDim.x * gridDim.z + 2 * (blockIdx.x + gridDim.x * blockIdx.z);
+        dy[0] = dg_c0 - dg_entry;                                   // prologue: kernel entry -> main loop
+        dy[1] = __builtin_amdgcn_s_memtime() - dg_loop_end;         // epilogue (stores issued, not necessarily landed)
+    }
+#endif
 }
 
 // the bf16 projection kernel: 16x16x32 MFMA shape (+4..9 % over the 32x32x16 shape at equal cycles: higher clock)
 __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_kernel(GemmBArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_t256_body<T256_BF16_16>(args, smem);
+}
+
+// MODE 3 on the 256 x 256 block tile (8 waves, one workgroup per CU)
+#define GB3_BM 256
+#define GB3_LDS_BYTES (8 * 32 * GB2_EPI_LD * 4)        // the epilogue's eight parking images (135,168 B) > the 3-slot ring (98,304 B)
+__global__ __launch_bounds__(512, 2) void iefvad_gemm_bf16_w256_kernel(GemmBArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_t256_body<T256_BF16_16P, GB3_BM>(args, smem);
 }
 
 // MODE 3: the same k-tile with the issue order pinned (A/B candidate of tools/gemm_tune_bf16)

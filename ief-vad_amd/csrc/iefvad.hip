@@ -150,6 +150,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GB3_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
     if (e == hipSuccess)
@@ -473,9 +476,17 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
 static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
     hipEvent_t e;
     if (a.N % GB2_BN == 0 && a.M % GB2_BM == 0 && a.K % GB2_BK == 0 && a.K >= 2 * GB2_BK) {
-        dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
         e = tm.begin(stage);
-        hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, a);   // pinned issue order: +1..3 %, same bits
+        // two bit-identical tilings: 256 x 256 / 8 waves / one workgroup per CU is 2-6 % faster with bias-type epilogues
+        // (in_proj, out_proj, heads, the refinement's first projection), 128 x 256 / 4 waves / two per CU with the refinement
+        // epilogue (residual read + two stores): tools/gemm_tune_bf16, profiles/r02_gemm_bf16_w256.log
+        if (a.M % GB3_BM == 0 && a.epi != EPI_REFINE && (a.M / GB3_BM) * (a.N / GB2_BN) * nz >= 256) {
+            dim3 grid((a.M / GB3_BM) * (a.N / GB2_BN), 1, nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_w256_kernel, grid, dim3(512), GB3_LDS_BYTES, stream, a);
+        } else {
+            dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, a);   // pinned issue order: +1..3 %, same bits
+        }
     } else {
         if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMMB_BK)
             return fail("gemm(bf16): shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM,

@@ -24,6 +24,9 @@ static float time_variant(const Variant& v, GemmBArgs g, int iters) {
         if (v.kind == 2) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_m32_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        } else if (v.kind == 5) {
+            dim3 grid((g.M / GB3_BM) * (g.N / GB2_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_w256_kernel, grid, dim3(512), GB3_LDS_BYTES, 0, g);
         } else if (v.kind == 4) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
@@ -57,6 +60,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_m32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB3_LDS_BYTES));
     const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"m32 bias  C32", 2, EPI_BIAS, 1, true, false},
                           {"m32 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"m32 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
                           {"m32 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"m32 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
@@ -66,7 +70,10 @@ int main(int argc, char** argv) {
                           {"m16 none (no stores)", 3, EPI_BIAS, 1, false, false},
                           {"pipe bias  C32", 4, EPI_BIAS, 1, true, false}, {"pipe relu  C16 only", 4, EPI_BIAS_RELU, 1, false, true},
                           {"pipe refine C32+C16", 4, EPI_REFINE, 1, true, true}, {"pipe bias  C32 z=2", 4, EPI_BIAS, 2, true, false},
-                          {"pipe none (no stores)", 4, EPI_BIAS, 1, false, false}};
+                          {"pipe none (no stores)", 4, EPI_BIAS, 1, false, false},
+                          {"w256 bias  C32", 5, EPI_BIAS, 1, true, false}, {"w256 relu  C16 only", 5, EPI_BIAS_RELU, 1, false, true},
+                          {"w256 refine C32+C16", 5, EPI_REFINE, 1, true, true}, {"w256 bias  C32 z=2", 5, EPI_BIAS, 2, true, false},
+                          {"w256 none (no stores)", 5, EPI_BIAS, 1, false, false}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int ni = 0; ni < 2; ++ni) {
         GemmBArgs g; memset(&g, 0, sizeof(g));
@@ -88,6 +95,10 @@ int main(int argc, char** argv) {
             time_variant(vs[13], g, 1); CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
             size_t bad3 = 0; for (size_t q = 0; q < c3.size(); ++q) bad3 += (c3[q] != c2[q]);
             printf("N=%d: pipe vs m16: %zu mismatching elements of %zu\n", g.N, bad3, c3.size());
+            CK(hipMemset(C, 0, c1.size() * 4));
+            time_variant(vs[18], g, 1); CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
+            bad3 = 0; for (size_t q = 0; q < c3.size(); ++q) bad3 += (c3[q] != c2[q]);
+            printf("N=%d: w256 vs m16: %zu mismatching elements of %zu\n", g.N, bad3, c3.size());
         }
         std::vector<std::vector<float>> t(nv);
         for (int r = 0; r < rounds; ++r)
@@ -100,18 +111,29 @@ int main(int argc, char** argv) {
         }
     }
 #ifdef GB2_CLOCK_DIAG
-    {   // in-kernel clock of the v2 main loop under sustained load (>= 1 s of back-to-back launches first)
-        unsigned long long* dclk; CK(hipMalloc(&dclk, 16 * 2048 * 4));
+    for (int which = 0; which < 2; ++which) {   // in-kernel clock and per-k-tile cycle split of the main loop under sustained load
+        unsigned long long* dclk; CK(hipMalloc(&dclk, 64 * 8192));
         GemmBArgs g; memset(&g, 0, sizeof(g));
         g.M = M; g.N = 768; g.K = K; g.lda = K; g.ldc = 768; g.epi = EPI_BIAS;
         g.p[0].A = A; g.p[0].W = W; g.p[0].bias = bias; g.p[0].C = nullptr; g.p[0].Cb = Cb; g.p[0].C2 = (float*)dclk; g.p[1] = g.p[0];
-        dim3 grid((M / GB2_BM) * (768 / GB2_BN), 1, 1);
-        for (int it = 0; it < 10000; ++it) hipLaunchKernelGGL(iefvad_gemm_bf16_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        dim3 grid((M / (which ? GB3_BM : GB2_BM)) * (768 / GB2_BN), 1, 1);
+        for (int it = 0; it < 4000; ++it) {
+            if (which) hipLaunchKernelGGL(iefvad_gemm_bf16_w256_kernel, grid, dim3(512), GB3_LDS_BYTES, 0, g);
+            else hipLaunchKernelGGL(iefvad_gemm_bf16_pipe_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        }
         CK(hipDeviceSynchronize());
-        std::vector<unsigned long long> c(2 * grid.x); CK(hipMemcpy(c.data(), dclk, c.size() * 8, hipMemcpyDeviceToHost));
-        std::vector<double> ghz; for (size_t b = 0; b < grid.x; ++b) ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1);
-        std::sort(ghz.begin(), ghz.end());
-        printf("bf16 v2 main loop in-kernel clock: median %.3f GHz (min %.3f max %.3f), loop cycles median %llu\n", ghz[ghz.size() / 2], ghz.front(), ghz.back(), c[2 * (grid.x / 2)]);
+        std::vector<unsigned long long> c(7 * grid.x); CK(hipMemcpy(c.data(), dclk, c.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> ghz; std::vector<unsigned long long> cyc, p0, p1, p2, q0, q1;
+        for (size_t b = 0; b < grid.x; ++b) { q0.push_back(c[5 * grid.x + 2 * b]); q1.push_back(c[5 * grid.x + 2 * b + 1]); }
+        std::sort(q0.begin(), q0.end()); std::sort(q1.begin(), q1.end());
+        for (size_t b = 0; b < grid.x; ++b) {
+            ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1); cyc.push_back(c[2 * b]);
+            p0.push_back(c[2 * grid.x + 3 * b]); p1.push_back(c[2 * grid.x + 3 * b + 1]); p2.push_back(c[2 * grid.x + 3 * b + 2]);
+        }
+        std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end()); std::sort(p0.begin(), p0.end()); std::sort(p1.begin(), p1.end()); std::sort(p2.begin(), p2.end());
+        printf("%s (bf16 out): clock median %.3f GHz; wave 0 main loop %llu cycles (24 k-tiles, ideal 24 x 512 = 12288); per k-tile over the first 22: body %.0f, vmcnt/lgkmcnt wait %.0f, barrier %.0f\n",
+               which ? "w256 256x256 8 waves" : "pipe 128x256 4 waves x 2", ghz[ghz.size() / 2], cyc[cyc.size() / 2], p0[p0.size() / 2] / 22.0, p1[p1.size() / 2] / 22.0, p2[p2.size() / 2] / 22.0);
+        printf("    prologue (entry -> loop) %llu cycles, epilogue (loop end -> last store issued) %llu cycles (medians over workgroups)\n", q0[q0.size() / 2], q1[q1.size() / 2]);
     }
 #endif
     return 0;
