@@ -443,7 +443,15 @@ __device__ __forceinline__ void gemm_t256_body(const GemmBArgs& args, float* sme
         // which of the first 512 workgroups share a CU is not documented: > 0 assumes (b, b + 256), < 0 assumes consecutive
         // workgroups of one XCD, (b, b + 8)
         const bool late = args.stagger > 0 ? (lin >= 256 && lin < 512) : (lin < 512 && ((lin >> 3) & 1));
-        if (late)
+        if (n >= 1000) {
+            // uniform phases: the first 512 workgroups (every initial resident) start at one of 64 evenly spaced offsets
+            // over (n - 1000) x 64 x 64 cycles, so that chip-wide the store traffic is a steady stream, not a burst per tile
+            if (lin < 512) {
+                const int ph = (lin * 29) & 63;
+                for (int w = 0; w < ph; ++w)
+                    for (int u = 0; u < n - 1000; ++u) __builtin_amdgcn_s_sleep(1);
+            }
+        } else if (late)
             for (int w = 0; w < n; ++w) __builtin_amdgcn_s_sleep(127);
     }
 
