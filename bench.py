@@ -55,7 +55,8 @@ GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
-GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel", "bf16": "iefvad_gemm_bf16_pipe_kernel",
+GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
+               "bf16": "iefvad_gemm_bf16_w256_kernel (bias-type epilogues) + iefvad_gemm_bf16_pipe_kernel (refinement epilogue)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",

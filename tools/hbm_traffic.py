@@ -2,7 +2,8 @@
 """HBM-side bytes per launch of one kernel from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
 separately, as MI355X_MICROARCH.md's HBM section prescribes), calibrated on iefvad_layernorm_kernel, which streams a
 known byte count in the same passes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled when the calibration
-shows 1/2).  usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring>
+shows 1/2).  The kernel argument may name several substrings joined by '|' (two tilings of one GEMM): the mean is over all
+their launches.   usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring>
                                    <rows per launch> <out.json> "<source description>" """
 import csv
 import json
@@ -17,7 +18,11 @@ def means(path, counter):
         if r["Counter_Name"] != counter:
             continue
         acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    out = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    hits = [x for k, v in acc.items() if any(sub in k for sub in kname.split("|")) for x in v]
+    if hits:
+        out[kname] = (sum(hits) / len(hits), len(hits))
+    return out
 
 
 f, w = means(fetch_csv, "FETCH_SIZE"), means(write_csv, "WRITE_SIZE")
