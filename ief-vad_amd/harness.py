@@ -700,18 +700,26 @@ class ScoreComm:
         self._last_error = _lib.last_error
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # every failure below is made SYMMETRIC: a rank that raised alone would leave the others blocked in a collective
         ident = [None]
         if self.rank == 0:
             buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
             if self._lib.iefvad_comm_unique_id(buf) != 0:
-                raise RuntimeError("iefvad_comm_unique_id: " + self._last_error())
-            ident = [bytes(buf.raw)]
+                ident = ["iefvad_comm_unique_id: " + self._last_error()]      # a str instead of the id: everybody raises
+            else:
+                ident = [bytes(buf.raw)]
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(ident[0], bytes):
+            raise RuntimeError(str(ident[0]))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self._lib.iefvad_comm_create(C.c_char_p(ident[0]), self.world, self.rank, C.byref(self._h))
-        if rc != 0:
-            raise RuntimeError("iefvad_comm_create: " + self._last_error())
+        err = "" if rc == 0 else "iefvad_comm_create: " + self._last_error()
+        bad = torch.tensor([1 if rc != 0 else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if int(bad.item()) != 0:
+            self.close()
+            raise RuntimeError(err or "iefvad_comm_create failed on another rank")
         self.nranks = int(self._lib.iefvad_comm_nranks(self._h))      # what RCCL reports
 
     def gather(self, local: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
