@@ -56,7 +56,8 @@ TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
-               "bf16": "iefvad_gemm_bf16_w256_kernel (bias-type epilogues) + iefvad_gemm_bf16_pipe_kernel (refinement epilogue)",
+               "bf16": "iefvad_gemm_bf16_w256_kernel (bias-type epilogues) + iefvad_gemm_bf16_pipe_kernel (refinement epilogue) "
+                       "+ iefvad_heads_fused_bf16_kernel (heads + fusion)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -165,6 +166,10 @@ def roofline_block(compute, stage, steps, rows_per_step):
          "algorithmic_flops_per_launch": flops / launches,
          "definition": "achieved = algorithmic GEMM FLOPs (SURVEY 8d, 47,185,920 per snippet) / sum of the kernel's "
                        "launch durations (hipEvents on the launch stream, inside the timed region)"}
+    if compute == "bf16":
+        r["note"] = ("the heads launch of each pass is iefvad_heads_fused_bf16_kernel: both modalities' heads AND the "
+                     "precision-weighted fusion (2 expf + 2 divisions per element in its epilogue); its whole duration is "
+                     "counted as GEMM time here")
     ppm = PRODUCTS_PER_MAC[compute]
     if ppm > 1:
         r["mfma_pipe_util"] = achieved * ppm / peak

@@ -22,6 +22,7 @@
 #include "gemm_bf16.h"
 #include "gemm_split.h"
 #include "rowops.h"
+#include "heads_fused_bf16.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -50,6 +51,7 @@ struct iefvad_handle {
     iefvad_config cfg;
     int device;
     bool weights_set;
+    bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
     float* arena;          // one allocation holding every repacked weight
     size_t arena_floats;
     // pointers into the arena
@@ -142,6 +144,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (!h) return fail("iefvad_create: out of host memory");
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
+    { const char* v = getenv("IEFVAD_NO_HEADS_FUSION"); h->no_heads_fusion = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -152,6 +155,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB3_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_heads_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HF_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
@@ -749,8 +755,40 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             cur[1] = xbuf[1];
         }
 
+        // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion, heads_fused_bf16.h.  The four
+        // head tensors are stored only if the caller asked for them.
+        const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= 256;
+        if (heads_fused) {
+            HeadsFusedArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            for (int m = 0; m < 2; ++m) { ha.A[m] = xb[m]; ha.W[m] = h->head_wb[m]; ha.bias[m] = h->head_b[m]; }
+            ha.mu[0] = out->image_mu ? mu_i : nullptr;
+            ha.lv[0] = out->image_logvar ? lv_i : nullptr;
+            ha.mu[1] = out->event_mu ? mu_e : nullptr;
+            ha.lv[1] = out->event_logvar ? lv_e : nullptr;
+            ha.n[0] = out->w_i ? out->w_i + row0 * D : nullptr;
+            ha.n[1] = out->w_e ? out->w_e + row0 * D : nullptr;
+            ha.z = z;
+            ha.zb = zb;
+            const bool means = out->w_i_mean || out->w_e_mean;
+            ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 24 of its 768 floats per row
+            ha.M = rows; ha.factor = factor; ha.eps = c.epsilon;
+            hipEvent_t e = tm.begin(ST_HEAD);
+            hipLaunchKernelGGL(iefvad_heads_fused_bf16_kernel, dim3((rows / HF_BM) * HF_NBLK), dim3(512), HF_LDS_BYTES, stream, ha);
+            tm.end(e);
+            tm.gemm_launches += 1;
+            HIP_TRY(hipGetLastError());
+            if (means) {
+                e = tm.begin(ST_FUSION);
+                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
+                                   out->w_i_mean ? out->w_i_mean + row0 : nullptr, out->w_e_mean ? out->w_e_mean + row0 : nullptr, rows);
+                tm.end(e);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+
         // 2. mu / logvar heads (imf_vad.py:125-128): one [768 -> 1536] projection per modality
-        {
+        if (!heads_fused) {
             Proj p;
             memset(&p, 0, sizeof(p));
             p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
@@ -763,7 +801,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         }
 
         // 3. precision weights + fusion (imf_vad.py:130-144), fp32 in both modes
-        {
+        if (!heads_fused) {
             FusionArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.mu_i = mu_i; fa.lv_i = lv_i; fa.mu_e = mu_e; fa.lv_e = lv_e;

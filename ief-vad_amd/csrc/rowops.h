@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
 // (/root/reference/model/imf_vad.py:130-144):
 //   w_m = factor * exp(-logvar_m) ; den = w_i + w_e + eps ; n_m = w_m / den ; z = n_i*mu_i + n_e*mu_e
 // The literal formula is kept (including its inf/inf = NaN behaviour for logvar < -88.7).
+// one element of the fusion; the literal operation order of the reference (shared with heads_fused_bf16.h)
+__device__ __forceinline__ void fuse_elem(float mi, float li, float me, float le, float factor, float eps,
+                                          float& ni, float& ne, float& z) {
+    const float wi = __fmul_rn(factor, expf(-li));
+    const float we = __fmul_rn(factor, expf(-le));
+    const float den = __fadd_rn(__fadd_rn(wi, we), eps);
+    ni = wi / den;
+    ne = we / den;
+    z = __fadd_rn(__fmul_rn(ni, mi), __fmul_rn(ne, me));
+}
+
 struct FusionArgs {
     const float* mu_i; const float* lv_i; const float* mu_e; const float* lv_e;   // [N, 768]
     float* n_i; float* n_e;     // [N, 768], nullable
@@ -116,12 +127,9 @@ __global__ __launch_bounds__(256) void iefvad_fusion_kernel(FusionArgs a) {
         f32x4 ni, ne, z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float wi = __fmul_rn(a.factor, expf(-li[e]));
-            const float we = __fmul_rn(a.factor, expf(-le[e]));
-            const float den = __fadd_rn(__fadd_rn(wi, we), a.eps);
-            ni[e] = wi / den;
-            ne[e] = we / den;
-            z[e] = __fadd_rn(__fmul_rn(ni[e], mi[e]), __fmul_rn(ne[e], me[e]));
+            float nie, nee, ze;
+            fuse_elem(mi[e], li[e], me[e], le[e], a.factor, a.eps, nie, nee, ze);
+            ni[e] = nie; ne[e] = nee; z[e] = ze;
             si += ni[e];
             se += ne[e];
             zm = amax_fold(zm, z[e]);

@@ -71,6 +71,38 @@ def test_bf16_scores_mode_and_microbatch_bit_identical():
     assert (b["w_i_mean"] - a["w_i"].mean(-1)).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("outputs,overflow", [("full", False), ("scores", False), ("full", True)])
+def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypatch, outputs, overflow):
+    """bf16 mode runs the heads of both modalities and the fusion as ONE kernel once a micro-batch fills the chip
+    (csrc/heads_fused_bf16.h; >= 22 chunks).  Same k order, same fusion operations: every output must equal the two-kernel
+    path bit for bit (IEFVAD_NO_HEADS_FUSION=1 at model creation), the row means of the weights to fp32 rounding (their
+    partial sums are combined in another order).  `overflow`: a log-variance column that overflows the literal formula
+    (inf / inf = NaN, imf_vad.py:135-142), without refinement steps so that the NaN stays in its column."""
+    K = 0 if overflow else 3
+    sd = synth.make_state_dict(7, 768, 2, K)
+    if overflow:
+        sd["temporal.image_logvar.bias"] = sd["temporal.image_logvar.bias"].clone()
+        sd["temporal.image_logvar.bias"][5] = -95.0
+        sd["temporal.event_logvar.bias"] = sd["temporal.event_logvar.bias"].clone()
+        sd["temporal.event_logvar.bias"][5] = -95.0
+    img, ev = synth.make_inputs(33, 48)
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    with torch.no_grad():
+        fused = make_model(2, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_NO_HEADS_FUSION", "1")
+        plain = make_model(2, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
+    assert set(fused) == set(plain)
+    for k in fused:
+        a, b = fused[k].float(), plain[k].float()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), k
+        if k in ("w_i_mean", "w_e_mean"):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6, equal_nan=True), k
+        else:
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), k
+    if overflow:
+        assert torch.isnan(fused["fused"][..., 5]).all() and torch.isfinite(fused["fused"][..., :5]).all()
+
+
 def test_xd_shaped_set_auc_and_ap_parity_bf16():
     """BASELINE config 3: XD-Violence-sized synthetic set (753 videos, ~145 k snippets), bf16 projections,
     AUC and AP (XD selects by AP, xd_train.py:114) equal to 4 d.p. against the fp32 CPU oracle."""
