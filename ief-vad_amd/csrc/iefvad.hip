@@ -23,6 +23,7 @@
 #include "gemm_split.h"
 #include "rowops.h"
 #include "heads_fused_bf16.h"
+#include "outproj_ln_bf16.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -52,6 +53,7 @@ struct iefvad_handle {
     int device;
     bool weights_set;
     bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
+    bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
     float* arena;          // one allocation holding every repacked weight
     size_t arena_floats;
     // pointers into the arena
@@ -145,6 +147,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
     { const char* v = getenv("IEFVAD_NO_HEADS_FUSION"); h->no_heads_fusion = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_NO_LN_FUSION"); h->no_ln_fusion = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -158,6 +161,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_heads_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HF_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OL_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
@@ -725,6 +731,30 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             }
             tm.end(e);
             HIP_TRY(hipGetLastError());
+
+            // out_proj + residual + LayerNorm(s) in one row-owning kernel (bf16 mode, full grids): outproj_ln_bf16.h
+            const bool ln_fused = bf && !h->no_ln_fusion && rows % OL_BM == 0 && (rows / OL_BM) * 2 >= 256;
+            if (ln_fused) {
+                OutLnArgs oa;
+                memset(&oa, 0, sizeof(oa));
+                for (int m = 0; m < 2; ++m) {
+                    OutLnProblem& q = oa.p[m];
+                    q.A = attb[m]; q.W = h->out_wb[m][l]; q.bias = h->out_b[m][l]; q.R = cur[m];
+                    q.g1 = h->norm_w[m][l]; q.b1 = h->norm_b[m][l];
+                    if (l == L - 1) { q.g2 = h->whiten_w[m]; q.b2 = h->whiten_b[m]; }
+                    q.y = (l < L - 1) ? xbuf[m] : nullptr;      // fp32 rows are only the next layer's residual
+                    q.yb = xb[m];
+                }
+                oa.M = rows; oa.eps = 1e-5f;
+                e = tm.begin(ST_OUT);
+                hipLaunchKernelGGL(iefvad_outproj_ln_bf16_kernel, dim3(rows / OL_BM, 2), dim3(512), OL_LDS_BYTES, stream, oa);
+                tm.end(e);
+                tm.gemm_launches += 1;
+                HIP_TRY(hipGetLastError());
+                cur[0] = xbuf[0];
+                cur[1] = xbuf[1];
+                continue;
+            }
 
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
