@@ -57,7 +57,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROAR
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
                "bf16": "iefvad_gemm_bf16_w256_kernel (bias-type epilogues) + iefvad_gemm_bf16_pipe_kernel (refinement epilogue) "
-                       "+ iefvad_heads_fused_bf16_kernel (heads + fusion)",
+                       "+ iefvad_heads_fused_bf16_kernel (heads + fusion) + iefvad_outproj_ln_bf16_kernel (out_proj + LayerNorm)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -167,9 +167,14 @@ def roofline_block(compute, stage, steps, rows_per_step):
          "definition": "achieved = algorithmic GEMM FLOPs (SURVEY 8d, 47,185,920 per snippet) / sum of the kernel's "
                        "launch durations (hipEvents on the launch stream, inside the timed region)"}
     if compute == "bf16":
-        r["note"] = ("the heads launch of each pass is iefvad_heads_fused_bf16_kernel: both modalities' heads AND the "
-                     "precision-weighted fusion (2 expf + 2 divisions per element in its epilogue); its whole duration is "
-                     "counted as GEMM time here")
+        pure_flops = (4 * (2 * D * 3 * D) + K_STEPS * 2 * (2 * D * D)) * rows_per_step      # in_proj + refinement launches only
+        pure_ms = (stage["qkv_gemm_ms"] + stage["refine_gemm_ms"]) / steps
+        r["achieved_pure_projection_launches"] = pure_flops / (pure_ms * 1e-3) / 1e12
+        r["note"] = ("two of the 25 projection launches of a pass carry more than a projection and are counted whole as GEMM "
+                     "time: iefvad_heads_fused_bf16_kernel (both modalities' heads AND the precision-weighted fusion) and "
+                     "iefvad_outproj_ln_bf16_kernel (out_proj + residual + LayerNorm); the stand-alone LayerNorm / fusion "
+                     "kernels then do not run (layernorm_ms = 0).  achieved_pure_projection_launches = the same quantity over the "
+                     "22 launches that are projections only (in_proj, refinement)")
     ppm = PRODUCTS_PER_MAC[compute]
     if ppm > 1:
         r["mfma_pipe_util"] = achieved * ppm / peak

@@ -29,7 +29,7 @@ for mode in bf16 bf16x6; do
       -d "$O/pmc_write_$mode" -o p -- python3 "$B" --steps 1 --warmup 1 --chunks 1024 --compute $mode $QUIET > /dev/null 2> "$O/pmc_write_$mode.log"
   python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_$mode" "$O/pmc_fetch_$mode" "$O/pmc_write_$mode" > "$O/pmc_summary_$mode.txt" 2>&1
 done
-K="iefvad_gemm_bf16_pipe_kernel|iefvad_gemm_bf16_w256_kernel|iefvad_heads_fused_bf16_kernel"
+K="iefvad_gemm_bf16_pipe_kernel|iefvad_gemm_bf16_w256_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_bf16_kernel"
 python3 "$R/tools/hbm_traffic.py" "$(find "$O/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)" "$(find "$O/pmc_write_bf16" -name '*counter_collection.csv' | head -1)" \
     "$K" 262144 "$O/gemm_bf16_hbm_traffic.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024 --compute bf16 (one micro-batch of 1024 chunks = 262144 rows per launch), MI355X, round 2" > /dev/null 2>&1
 K=iefvad_gemm_split_n128_kernel

@@ -28,12 +28,17 @@ def means(path, counter):
 f, w = means(fetch_csv, "FETCH_SIZE"), means(write_csv, "WRITE_SIZE")
 pick = lambda d, sub: next((v for k, v in d.items() if sub in k), None)
 ln_f, ln_w = pick(f, "iefvad_layernorm_kernel"), pick(w, "iefvad_layernorm_kernel")
+cal_name = "iefvad_layernorm_kernel"
 ln_bytes = 2 * rows * 768 * 4                                  # both modalities, one fp32 tensor in, one out
+if ln_f is None:        # bf16 mode with the fused out_proj + LayerNorm kernel: calibrate on the scorer (reads z once)
+    cal_name = "iefvad_scorer_kernel"
+    ln_f, ln_w = pick(f, cal_name), pick(w, cal_name)
+    ln_bytes = rows * 768 * 4
 fetch_scale = round(ln_bytes / (ln_f[0] * 1024))               # 2 on gfx950
 kf, kw = pick(f, kname), pick(w, kname)
 res = {"source": source, "kernel": kname, "launches_measured": kf[1], "rows_per_launch": rows,
        "FETCH_SIZE_KB_mean": kf[0], "WRITE_SIZE_KB_mean": kw[0],
-       "calibration": f"iefvad_layernorm_kernel streams {ln_bytes} B in and out: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
+       "calibration": f"{cal_name} streams {ln_bytes} B in: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
                       f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}",
        "read_bytes_per_launch": kf[0] * 1024 * fetch_scale, "write_bytes_per_launch": kw[0] * 1024,
        "traffic_bytes_per_launch": kf[0] * 1024 * fetch_scale + kw[0] * 1024}
