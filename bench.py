@@ -259,29 +259,33 @@ def ucf_eval(sd, margs, dev, a):
                        f"sigmoid, ordered scores, sklearn AUC/AP excluded from the clock)",
            "videos": nvid, "snippets": total}
 
-    def timed_scores(model, batch_chunks):
-        harness.score_loader(model, items[:4], T, dev, "ucfcrime", batch_chunks=batch_chunks)      # warm-up
+    def timed_scores(model, batch_chunks, lanes):
+        harness.score_loader(model, items[:8], T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)      # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        scores, cls, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks)
+        scores, cls, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)
         torch.cuda.synchronize()
         return scores, cls, time.perf_counter() - t0
 
     results = {}
-    modes = [("f32", (("per_video", 0), ("batched", 256)))]
+    modes = [("f32", (("per_video", 0, 1), ("per_video_4lanes", 0, 4), ("batched", 256, 1)))]
     if a.compute != "f32":
-        modes.append((a.compute, (("batched", 256),)))
+        modes.append((a.compute, (("batched", 256, 1),)))
     for compute, patterns in modes:
         model = make_model(sd, margs, dev, a, compute, outputs="scores")
-        for name, bc in patterns:
-            scores, cls, dt = timed_scores(model, bc)
+        for name, bc, lanes in patterns:
+            scores, cls, dt = timed_scores(model, bc, lanes)
             res = harness.evaluate_scores(scores, cls, gt, "ucfcrime", verbose=False)
             key = f"{name}_{compute}"
             results[key] = scores
             out[key] = {"snippets_per_s": total / dt, "seconds": dt, "auc": res["roc"], "ap": res["ap"],
                         "ano_auc": res["ano_auc"],
-                        "pattern": "one forward per video (test.py:76-117)" if bc == 0 else
+                        "pattern": ("one forward per video (test.py:76-117)" + (f", consecutive videos on {lanes} HIP streams "
+                                    "(same kernels, bit-identical scores)" if lanes > 1 else "")) if bc == 0 else
                                    f"chunks of consecutive videos packed into forwards of >= {bc} chunks"}
+        if "per_video_4lanes_f32" in results and compute == "f32":
+            out["per_video_4lanes_f32"]["bit_identical_to_per_video_f32"] = bool(all(
+                np.array_equal(x, y) for x, y in zip(results["per_video_4lanes_f32"], results["per_video_f32"])))
         del model
     # CPU oracle in the reference's per-video pattern on a bounded prefix of the same list
     oracle = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K_STEPS, nu=8))

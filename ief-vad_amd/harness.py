@@ -256,14 +256,19 @@ class _PinnedStager:
 
 
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
-                 label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True):
+                 label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True, lanes: int = 1):
     """Per-video sigmoid scores and mean fusion weights, in loader order.
 
     batch_chunks == 0: one forward per video with B = that video's chunk count -- the reference's call
     pattern (test.py:76-117).  batch_chunks > 0: chunks of consecutive videos are packed into one
     forward of up to `batch_chunks` chunks; legal because chunks are independent batch rows
     (imf_vad.py:115 attends within a chunk), and the trailing all-zero chunk of a len % 256 == 0 video,
-    whose rows the reference slices away (test.py:121), is not computed when `skip_empty_chunks`."""
+    whose rows the reference slices away (test.py:121), is not computed when `skip_empty_chunks`.
+
+    lanes > 1 (HIP devices, `iefvad_amd.MMFMIL`): consecutive forwards go round-robin to `lanes` HIP streams, each with a
+    lane of the model (`MMFMIL.lanes`: same parameters, own library handle and workspace) and its own pinned staging.
+    Same kernels on the same inputs, so every score is bit-identical to lanes = 1; what changes is that the one- and
+    two-chunk forwards of the per-video pattern, each of which fills a fraction of the chip, overlap."""
     classes: List[str] = []
     pend: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
     pend_chunks = 0
@@ -276,12 +281,30 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     spans: List[Tuple[int, int]] = []          # (offset into the concatenated device vectors, valid length) per video
     total = 0
 
-    stager = _PinnedStager(device) if torch.device(device).type == 'cuda' else None
+    on_gpu = torch.device(device).type == 'cuda'
+    nl = lanes if (on_gpu and lanes > 1 and hasattr(model, 'lanes')) else 1
+    models = model.lanes(nl) if nl > 1 else [model]
+    stagers = [_PinnedStager(device) if on_gpu else None for _ in range(nl)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(nl)] if nl > 1 else [None]
+    if nl > 1:
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(device))     # e.g. a `model.to(device)` still in flight
+    nflush = 0
 
     def flush():
-        nonlocal pend, pend_chunks, total
+        nonlocal nflush
         if not pend:
             return
+        k = nflush % nl
+        nflush += 1
+        if nl > 1:
+            with torch.cuda.stream(streams[k]):
+                flush_on(models[k], stagers[k])
+        else:
+            flush_on(models[0], stagers[0])
+
+    def flush_on(model, stager):
+        nonlocal pend, pend_chunks, total
         # dtype as the files hold it (dataset.py:37-38,49-50); the model widens with `.to(torch.float)` per modality
         # (imf_vad.py:41-42), so a batch that mixes dtypes -- across videos OR between the two modalities -- is widened
         # to fp32 here rather than narrowed to the first tensor's type
@@ -320,6 +343,9 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             if batch_chunks <= 0 or pend_chunks >= batch_chunks:
                 flush()
         flush()
+        if nl > 1:
+            for s in streams:
+                torch.cuda.current_stream(device).wait_stream(s)
         if dev_prob:
             prob = torch.cat(dev_prob).cpu().numpy()
             wi = torch.cat(dev_wi).cpu().numpy()
@@ -507,14 +533,15 @@ def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch
 
 
 def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,
-         batch_chunks: int = 0, normal_keys=('Normal',)):
+         batch_chunks: int = 0, normal_keys=('Normal',), lanes: int = 1):
     """Same positional signature and return value as the reference's `test()` (test.py:46-56;
     ucf_test.py:16-26; xd_test.py passes `label_map` as an extra positional, :23).
     Returns (ROC1, AP1) -- or (ROC1, AP1, attn_weights, labels) when attn=True, where attn_weights is the
     empty list the reference also returns (it never fills it, test.py:73,209-210)."""
     model.to(device)
     model.eval()
-    scores, classes, wi, we = score_loader(model, test_loader, maxlen, device, args.dataset, label_map, batch_chunks)
+    scores, classes, wi, we = score_loader(model, test_loader, maxlen, device, args.dataset, label_map, batch_chunks,
+                                           lanes=lanes)
     res = evaluate_scores(scores, classes, gt, args.dataset, verbose=True, normal_keys=normal_keys)
     test.last_result = dict(res, scores=scores, classes=classes, w_i_mean=wi, w_e_mean=we)
     if vis:

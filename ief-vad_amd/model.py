@@ -237,19 +237,35 @@ class MMFMIL(nn.Module):
             raise RuntimeError("iefvad_set_weights: " + _lib.last_error())
         self._weights_sig = sig
 
+    def lanes(self, n: int):
+        """`n` forward lanes over ONE set of parameters: lane 0 is this module, the others are shallow copies that share
+        `self.temporal` (the same Parameter objects) and own a library handle, repacked weights and workspace each, so that
+        forwards issued on different HIP streams can run at the same time (harness.score_loader(lanes=...): the one-chunk
+        forwards of the reference's per-video loop leave most of the chip idle).  Cached on the module."""
+        import copy
+        have = self.__dict__.setdefault("_lane_copies", [])
+        while len(have) < n - 1:
+            c = copy.copy(self)
+            c.__dict__["_lane_copies"] = []
+            c._handle = c._handle_key = c._weights_sig = c._workspace = None
+            have.append(c)
+        return [self] + have[:max(n - 1, 0)]
+
     def refresh_weights(self):
         """Force the library to re-read (and re-pack / re-split) the parameters on the next forward.  The shim notices
         `load_state_dict`, `.to()`, optimizer steps and any in-place op on a Parameter (they change the storage pointer
         or the tensor version), but NOT writes made through `param.data` (e.g. `p.data.mul_(0.999)` in an EMA or a
         clipping utility): those bypass the version counter, so call this after them."""
         self._weights_sig = None
+        for c in self.__dict__.get("_lane_copies", []):
+            c._weights_sig = None
 
     def load_state_dict(self, *args, **kw):
-        self._weights_sig = None
+        self.refresh_weights()
         return super().load_state_dict(*args, **kw)
 
     def _apply(self, fn, *args, **kw):
-        self._weights_sig = None
+        self.refresh_weights()
         return super()._apply(fn, *args, **kw)
 
     # ------------------------------------------------------------------ forward

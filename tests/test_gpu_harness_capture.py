@@ -62,6 +62,32 @@ def test_per_video_and_packed_scores_are_bit_identical_in_f32(config1):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("outputs", ["scores", "full"])
+def test_per_video_loop_on_several_streams_is_bit_identical(config1, outputs):
+    """score_loader(lanes=3): consecutive videos go to three HIP streams, each with its own lane of the model (same
+    Parameters, own library handle / workspace / pinned staging).  Scores, weight means and their order must equal the
+    one-stream loop bit for bit; run twice, so that the cached lanes (and their hipGraphs) are reused; then through
+    harness.test against the reference capture; then after load_state_dict of other weights (every lane must notice)."""
+    g, args, gt, sd = config1
+    model = gpu_model(sd, outputs=outputs).to("cuda:0").eval()
+    s1, c1, wi1, we1 = harness.score_loader(model, harness.get_test_loader(args), 256, "cuda:0", "ucfcrime")
+    for _ in range(2):
+        s3, c3, wi3, we3 = harness.score_loader(model, harness.get_test_loader(args), 256, "cuda:0", "ucfcrime", lanes=3)
+        assert c1 == c3 and len(s1) == len(s3)
+        for a, b in zip(s1 + wi1 + we1, s3 + wi3 + we3):
+            assert np.array_equal(a, b, equal_nan=True)
+    assert len(model.lanes(3)) == 3 and model.lanes(3)[1] is model.lanes(3)[1]
+    roc, ap = harness.test(args, model, harness.get_test_loader(args), 256, None, gt, "cuda:0", lanes=3)
+    assert abs(roc - float(g["roc"])) < 1e-4 and abs(ap - float(g["ap"])) < 1e-4
+    sd2 = synth.make_state_dict(77, 768, 2, 10)
+    model.load_state_dict(sd2)
+    t3, _, _, _ = harness.score_loader(model, harness.get_test_loader(args), 256, "cuda:0", "ucfcrime", lanes=3)
+    t1, _, _, _ = harness.score_loader(model, harness.get_test_loader(args), 256, "cuda:0", "ucfcrime")
+    for a, b in zip(t1, t3):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert not np.array_equal(np.concatenate(t1), np.concatenate(s1))
+
+
 @pytest.mark.parametrize("compute", ["f32", "bf16x6"])
 def test_streaming_file_pipeline_on_the_gpu(config1, compute):
     """harness.evaluate_files on cuda:0 (header pre-scan, read() into pinned staging, H2D on a side stream,
