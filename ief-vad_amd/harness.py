@@ -322,7 +322,7 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         else:
             wi = out['w_i'].reshape(-1, out['w_i'].shape[-1]).mean(dim=-1)     # test.py:131-136
             we = out['w_e'].reshape(-1, out['w_e'].shape[-1]).mean(dim=-1)
-        dev_prob.append(torch.sigmoid(logits).float())
+        dev_prob.append(logits.float())                      # sigmoid once, on the concatenated logits, after the loop
         dev_wi.append(wi.float())
         dev_we.append(we.float())
         off = total
@@ -347,7 +347,7 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             for s in streams:
                 torch.cuda.current_stream(device).wait_stream(s)
         if dev_prob:
-            prob = torch.cat(dev_prob).cpu().numpy()
+            prob = torch.sigmoid(torch.cat(dev_prob)).cpu().numpy()       # logits1[0:len_cur] -> sigmoid, test.py:119-121
             wi = torch.cat(dev_wi).cpu().numpy()
             we = torch.cat(dev_we).cpu().numpy()
         else:

@@ -202,14 +202,21 @@ class MMFMIL(nn.Module):
 
     def _ensure_weights(self, device: torch.device, stream: int):
         t = self.temporal
-        params = list(t.parameters())
+        # (owner's _parameters dict, name) of every parameter, resolved once: walking the module tree on every call costs
+        # more host time than the rest of a one-chunk forward's enqueue; looking the slots up each time still sees a
+        # Parameter that was re-assigned
+        slots = self.__dict__.get("_param_slots")
+        if slots is None:
+            slots = [(m._parameters, n) for m in t.modules() for n in m._parameters if m._parameters[n] is not None]
+            self.__dict__["_param_slots"] = slots
+        params = [d[n] for d, n in slots]
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        if sig == self._weights_sig:
+            return
         for p in params:
             if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("MMFMIL parameters must be contiguous fp32 tensors on the input's device "
                                    f"({device}); call model.to(device)")
-        sig = tuple((p.data_ptr(), p._version) for p in params)
-        if sig == self._weights_sig:
-            return
         w = _lib.Weights()
         for m, name in enumerate(("image", "event")):
             attn = getattr(t, f"{name}_attn_layers")
