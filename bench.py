@@ -268,9 +268,9 @@ def ucf_eval(sd, margs, dev, a):
         return scores, cls, time.perf_counter() - t0
 
     results = {}
-    modes = [("f32", (("per_video", 0, 1), ("per_video_4lanes", 0, 4), ("batched", 256, 1)))]
+    modes = [("f32", (("per_video", 0, 1), ("per_video_4lanes", 0, 4), ("batched", 64, 3)))]
     if a.compute != "f32":
-        modes.append((a.compute, (("batched", 256, 1),)))
+        modes.append((a.compute, (("batched", 128, 3),)))
     for compute, patterns in modes:
         model = make_model(sd, margs, dev, a, compute, outputs="scores")
         for name, bc, lanes in patterns:
@@ -282,7 +282,8 @@ def ucf_eval(sd, margs, dev, a):
                         "ano_auc": res["ano_auc"],
                         "pattern": ("one forward per video (test.py:76-117)" + (f", consecutive videos on {lanes} HIP streams "
                                     "(same kernels, bit-identical scores)" if lanes > 1 else "")) if bc == 0 else
-                                   f"chunks of consecutive videos packed into forwards of >= {bc} chunks"}
+                                   f"chunks of consecutive videos packed into forwards of >= {bc} chunks, forwards "
+                                   f"round-robin on {lanes} HIP streams (H2D of one overlaps the forward of another)"}
         if "per_video_4lanes_f32" in results and compute == "f32":
             out["per_video_4lanes_f32"]["bit_identical_to_per_video_f32"] = bool(all(
                 np.array_equal(x, y) for x, y in zip(results["per_video_4lanes_f32"], results["per_video_f32"])))

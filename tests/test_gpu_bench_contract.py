@@ -40,11 +40,12 @@ def test_default_line_structure_and_consistency():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     u = d["ucf_eval"]
     assert u["videos"] == 290 and 60000 < u["snippets"] < 80000
-    for k in ("per_video_f32", "batched_f32", "batched_bf16x6"):
+    for k in ("per_video_f32", "per_video_4lanes_f32", "batched_f32", "batched_bf16x6"):
         assert u[k]["snippets_per_s"] > 0
         assert u[k]["max_abs_score_diff_vs_oracle_on_sample"] <= 2e-6       # fp32 gate on sigmoid(logit)
         assert u[k]["abs_auc_diff_vs_oracle_on_sample"] <= 1e-4             # north star: AUC within 1e-4
     assert u["per_video_f32"]["x_cpu_oracle"] >= 10                          # north star: >= 10x the reference CPU path
+    assert u["per_video_4lanes_f32"]["bit_identical_to_per_video_f32"] is True
     for key, nvid in (("xd_eval", 753), ("shang_msad_eval", 438)):           # BASELINE configs 3 and 5: bf16 projections
         e = d[key]
         assert e["videos"] == nvid and e["compute"] == "bf16" and e["snippets_per_s"] > 0

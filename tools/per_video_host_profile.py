@@ -22,16 +22,21 @@ model = iefvad_amd.MMFMIL(14, 768, T, 768, 8, 2, 8, 10, 10, "cuda", margs, outpu
 model.load_state_dict(synth.make_state_dict(0, 768, 2, 10))
 model = model.to("cuda:0").eval()
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-harness.score_loader(model, items[:16], T, "cuda:0", "ucfcrime", lanes=lanes)
+bc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if len(sys.argv) > 3:
+    model = iefvad_amd.MMFMIL(14, 768, T, 768, 8, 2, 8, 10, 10, "cuda", margs, outputs="scores", compute=sys.argv[3])
+    model.load_state_dict(synth.make_state_dict(0, 768, 2, 10))
+    model = model.to("cuda:0").eval()
+harness.score_loader(model, items[:16], T, "cuda:0", "ucfcrime", lanes=lanes, batch_chunks=bc)
 torch.cuda.synchronize()
 for rep in range(2):
     t0 = time.perf_counter()
-    harness.score_loader(model, items, T, "cuda:0", "ucfcrime", lanes=lanes)
+    harness.score_loader(model, items, T, "cuda:0", "ucfcrime", lanes=lanes, batch_chunks=bc)
     torch.cuda.synchronize()
-    print(f"lanes={lanes}: {time.perf_counter() - t0:.4f} s for {nvid} videos")
+    print(f"lanes={lanes} batch_chunks={bc} {sys.argv[3] if len(sys.argv) > 3 else 'f32'}: {time.perf_counter() - t0:.4f} s for {nvid} videos")
 pr = cProfile.Profile()
 pr.enable()
-harness.score_loader(model, items, T, "cuda:0", "ucfcrime", lanes=lanes)
+harness.score_loader(model, items, T, "cuda:0", "ucfcrime", lanes=lanes, batch_chunks=bc)
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
