@@ -25,6 +25,9 @@ static float time_variant(const Variant& v, GemmBArgs g, int iters) {
         if (v.kind == 2) {
             dim3 grid((g.M / GB2_BM) * (g.N / GB2_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_m32_kernel, grid, dim3(256), GB2_LDS_BYTES, 0, g);
+        } else if (v.kind == 7) {
+            dim3 grid((g.M / GB3_BM) * (g.N / GB2_BN), 1, v.nz);
+            hipLaunchKernelGGL(iefvad_gemm_bf16_w256q_kernel, grid, dim3(512), GB3_LDS_BYTES, 0, g);
         } else if (v.kind == 6) {
             dim3 grid((g.M / GW_BM) * (g.N / GW_BN), 1, v.nz);
             hipLaunchKernelGGL(iefvad_gemm_bf16_wt128_kernel, grid, dim3(256), GW_LDS_BYTES, 0, g);
@@ -66,6 +69,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB2_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB3_LDS_BYTES));
     CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_wt128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GB3_LDS_BYTES));
     const Variant vs[] = {{"v1 bias  C32", 1, EPI_BIAS, 1, true, false}, {"m32 bias  C32", 2, EPI_BIAS, 1, true, false},
                           {"m32 bias  C16 only", 2, EPI_BIAS, 1, false, true}, {"m32 relu  C16 only", 2, EPI_BIAS_RELU, 1, false, true},
                           {"m32 refine C32+C16", 2, EPI_REFINE, 1, true, true}, {"m32 resid C32", 2, EPI_BIAS_RESID, 1, true, false},
@@ -81,7 +85,10 @@ int main(int argc, char** argv) {
                           {"w256 none (no stores)", 5, EPI_BIAS, 1, false, false},
                           {"wt128 bias  C32", 6, EPI_BIAS, 1, true, false}, {"wt128 relu  C16 only", 6, EPI_BIAS_RELU, 1, false, true},
                           {"wt128 refine C32+C16", 6, EPI_REFINE, 1, true, true}, {"wt128 bias  C32 z=2", 6, EPI_BIAS, 2, true, false},
-                          {"wt128 none (no stores)", 6, EPI_BIAS, 1, false, false}};
+                          {"wt128 none (no stores)", 6, EPI_BIAS, 1, false, false},
+                          {"w256q bias  C32", 7, EPI_BIAS, 1, true, false}, {"w256q relu  C16 only", 7, EPI_BIAS_RELU, 1, false, true},
+                          {"w256q refine C32+C16", 7, EPI_REFINE, 1, true, true}, {"w256q bias  C32 z=2", 7, EPI_BIAS, 2, true, false},
+                          {"w256q none (no stores)", 7, EPI_BIAS, 1, false, false}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int ni = 0; ni < 2; ++ni) {
         GemmBArgs g; memset(&g, 0, sizeof(g));
@@ -111,6 +118,10 @@ int main(int argc, char** argv) {
             time_variant(vs[23], g, 1); CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
             bad3 = 0; for (size_t q = 0; q < c3.size(); ++q) bad3 += (c3[q] != c2[q]);
             printf("N=%d: wt128 vs m16: %zu mismatching elements of %zu\n", g.N, bad3, c3.size());
+            CK(hipMemset(C, 0, c1.size() * 4));
+            time_variant(vs[28], g, 1); CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
+            bad3 = 0; for (size_t q = 0; q < c3.size(); ++q) bad3 += (c3[q] != c2[q]);
+            printf("N=%d: w256q vs m16: %zu mismatching elements of %zu\n", g.N, bad3, c3.size());
         }
         std::vector<std::vector<float>> t(nv);
         for (int r = 0; r < rounds; ++r)
