@@ -51,3 +51,28 @@ def test_attributes_used_by_callers():
     assert m.eval() is m and not m.training
     with pytest.raises(ValueError):
         make(1, outputs="everything")
+
+
+def test_lanes_share_parameters_and_notice_weight_changes():
+    """MMFMIL.lanes(n): shallow copies for concurrent forwards on several HIP streams.  They must hold the SAME Parameter
+    objects (one set of weights), own no library handle until they run, be cached, and be invalidated together with the
+    parent by load_state_dict / refresh_weights.  No GPU needed."""
+    m = make(2)
+    lanes = m.lanes(3)
+    assert len(lanes) == 3 and lanes[0] is m and lanes[1] is not m and lanes[1] is not lanes[2]
+    assert m.lanes(3)[1] is lanes[1] and m.lanes(2) == lanes[:2]                    # cached, prefix-stable
+    assert m.lanes(1) == [m]
+    for c in lanes[1:]:
+        assert c.temporal is m.temporal and c._handle is None and c._workspace is None
+        assert [id(p) for p in c.parameters()] == [id(p) for p in m.parameters()]
+        assert c.outputs == m.outputs and c.compute == m.compute
+    for c in lanes:
+        c._weights_sig = ("stale",)
+    m.load_state_dict(synth.make_state_dict(9, 768, 2, 2))
+    assert all(c._weights_sig is None for c in lanes)
+    for c in lanes:
+        c._weights_sig = ("stale",)
+    m.refresh_weights()
+    assert all(c._weights_sig is None for c in lanes)
+    # the state_dict does not grow lane entries
+    assert len(m.state_dict()) == len(make(2).state_dict())
