@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("B,compute", [(2, "f32"), (48, "bf16x6"), (48, "fp16x3")])
+@pytest.mark.parametrize("B,compute", [(2, "f32"), (48, "bf16x6"), (48, "fp16x3"), (64, "bf16")])
 def test_torch_free_c_driver_matches_python_path(tmp_path, B, compute):
-    """B = 2 runs the fp32 kernels; B = 48 is large enough for the split kernels of the bf16x6 / fp16x3 arithmetic."""
+    """B = 2 runs the fp32 kernels; B = 48 is large enough for the split kernels of the bf16x6 / fp16x3 arithmetic; B = 64 in the
+    bf16 mode for its two fused kernels (heads + fusion, out_proj + LayerNorm)."""
     L, K = 2, 3
     exe = tmp_path / "abi_driver"
     libdir = os.path.dirname(iefvad_amd.lib.LIB_PATH)
