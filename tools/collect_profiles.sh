@@ -40,6 +40,14 @@ echo "[4] per-video pattern"
 python3 "$R/tools/latency_probe.py" > "$O/latency.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_b1" -o t -- python3 "$R/tools/b1_loop.py" > /dev/null 2> "$O/trace_b1.log"
 python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_b1" -name '*kernel_stats.csv' | head -1)" "$O/b1_kernel_stats.csv" > /dev/null
+echo "[5] BASELINE config 5 (K=5, Shang+MSAD-sized, bf16): kernel stats + PMC counters"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_cfg5" -o t -- python3 "$R/tools/config5_profile.py" 5 > "$O/config5_run.log" 2> "$O/trace_cfg5.log"
+python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_cfg5" -name '*kernel_stats.csv' | head -1)" "$O/config5_kernel_stats.csv" > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv \
+    -d "$O/pmc_sq_cfg5" -o p -- python3 "$R/tools/config5_profile.py" 2 > /dev/null 2> "$O/pmc_sq_cfg5.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_cfg5" -o p -- python3 "$R/tools/config5_profile.py" 2 > /dev/null 2> "$O/pmc_fetch_cfg5.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_cfg5" -o p -- python3 "$R/tools/config5_profile.py" 2 > /dev/null 2> "$O/pmc_write_cfg5.log"
+python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_cfg5" "$O/pmc_fetch_cfg5" "$O/pmc_write_cfg5" > "$O/pmc_summary_config5.txt" 2>&1
 # keep the merge-back small: the raw traces are large
 find "$O" -name '*kernel_trace.csv' -size +8M -delete
 find "$O" -name '*.db' -delete
