@@ -222,8 +222,11 @@ def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
     dt, stage = run_mode(model, img, ev, steps)
     B = img.shape[0]
     value = B * T * steps / dt
+    roof = roofline_block(compute, stage, steps, B * T)
+    mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if compute == "f32" else 1024)           # library defaults
+    roof["traffic"] = traffic_from_profiles(compute, min(B, mb_eff) * T)
     out = {"compute": compute, "dtype": DTYPE[compute], "value": value, "unit": "snippets/s", "steps": steps,
-           "ms_per_step": dt / steps * 1e3, "roofline": roofline_block(compute, stage, steps, B * T),
+           "ms_per_step": dt / steps * 1e3, "roofline": roof,
            "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / 1e12,
            "stage_ms_per_step": {k: v / steps for k, v in stage.items() if k.endswith("_ms")}}
     del model
