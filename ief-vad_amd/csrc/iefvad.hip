@@ -24,6 +24,7 @@
 #include "rowops.h"
 #include "heads_fused_bf16.h"
 #include "outproj_ln_bf16.h"
+#include "refine_chain_bf16.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -54,6 +55,8 @@ struct iefvad_handle {
     bool weights_set;
     bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
     bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
+    bool no_chain;         // IEFVAD_NO_CHAIN=1: bf16 mode runs the refinement as 2K projection launches + the scorer kernel
+    char* chain_stream;    // bf16 mode: the refinement weights in the chain kernel's per-wave piece order (refine_chain_bf16.h)
     float* arena;          // one allocation holding every repacked weight
     size_t arena_floats;
     // pointers into the arena
@@ -148,6 +151,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     h->cfg = *cfg;
     { const char* v = getenv("IEFVAD_NO_HEADS_FUSION"); h->no_heads_fusion = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_LN_FUSION"); h->no_ln_fusion = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_NO_CHAIN"); h->no_chain = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -164,6 +168,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OL_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_refine_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RC_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
@@ -195,6 +202,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
     if (h->arena_b) (void)hipFree(h->arena_b);
+    if (h->chain_stream) (void)hipFree(h->chain_stream);
     if (h->arena_s) (void)hipFree(h->arena_s);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
@@ -307,6 +315,20 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
         for (int k = 0; k < K; ++k) {
             if (int rc = conv(&h->ref_w1b[k], h->ref_w1[k], DD)) return rc;
             if (int rc = conv(&h->ref_w2b[k], h->ref_w2[k], DD)) return rc;
+        }
+        if (K > 0) {
+            // the same bf16 matrices (and the fp32 biases) once more, in the chain kernel's per-wave piece order
+            if (!h->chain_stream) HIP_TRY(hipMalloc((void**)&h->chain_stream, chain_stream_bytes(K)));
+            ChainPackArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            for (int k = 0; k < K; ++k) {
+                pa.W[2 * k] = h->ref_w1b[k]; pa.bias[2 * k] = h->ref_b1[k];
+                pa.W[2 * k + 1] = h->ref_w2b[k]; pa.bias[2 * k + 1] = h->ref_b2[k];
+            }
+            pa.stream = h->chain_stream;
+            pa.K = K;
+            hipLaunchKernelGGL(iefvad_chain_pack_kernel, dim3(2048), dim3(256), 0, stream, pa);
+            HIP_TRY(hipGetLastError());
         }
     }
     if (h->cfg.compute == IEFVAD_COMPUTE_BF16X6) {
@@ -788,6 +810,8 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion, heads_fused_bf16.h.  The four
         // head tensors are stored only if the caller asked for them.
         const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= 256;
+        // 4 + 5 in one kernel (bf16 mode, full grids): the K refinement steps and the scorer with the state on chip, refine_chain_bf16.h
+        const bool chain = bf && K > 0 && !h->no_chain && h->chain_stream && rows % RC_BM == 0 && rows / RC_BM >= 256;
         if (heads_fused) {
             HeadsFusedArgs ha;
             memset(&ha, 0, sizeof(ha));
@@ -799,7 +823,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             ha.n[0] = out->w_i ? out->w_i + row0 * D : nullptr;
             ha.n[1] = out->w_e ? out->w_e + row0 * D : nullptr;
             ha.z = z;
-            ha.zb = zb;
+            ha.zb = chain ? nullptr : zb;      // the chain kernel reads the fp32 state only
             const bool means = out->w_i_mean || out->w_e_mean;
             ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 24 of its 768 floats per row
             ha.M = rows; ha.factor = factor; ha.eps = c.epsilon;
@@ -838,7 +862,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             fa.n_i = out->w_i ? out->w_i + row0 * D : nullptr;
             fa.n_e = out->w_e ? out->w_e + row0 * D : nullptr;
             fa.z = z;
-            fa.zb = bf ? zb : nullptr;
+            fa.zb = (bf && !chain) ? zb : nullptr;
             fa.n_i_mean = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
             fa.n_e_mean = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
             fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
@@ -847,6 +871,20 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             hipLaunchKernelGGL(iefvad_fusion_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
             tm.end(e);
             HIP_TRY(hipGetLastError());
+        }
+
+        if (chain) {
+            ChainArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.z_in = z; ca.stream = h->chain_stream; ca.cls_w = h->cls_w; ca.cls_b = h->cls_b;
+            ca.z_out = out->fused ? z : nullptr;        // in place: a workgroup reads its 64 rows before it writes them
+            ca.logits = logits;
+            ca.M = rows; ca.K = K; ca.lambda = c.lambda_ref; ca.wave_stride = (unsigned)chain_wave_stride_bytes(K);
+            hipEvent_t e = tm.begin(ST_REFINE);
+            hipLaunchKernelGGL(iefvad_refine_chain_bf16_kernel, dim3(rows / RC_BM), dim3(64 * RC_NW), RC_LDS_BYTES, stream, ca);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+            continue;
         }
 
         // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149); the state z stays fp32

@@ -107,6 +107,48 @@ def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypat
         assert torch.isnan(fused["fused"][..., 5]).all() and torch.isfinite(fused["fused"][..., :5]).all()
 
 
+@pytest.mark.parametrize("K,lam,outputs,B", [(1, 0.5, "full", 64), (3, 0.3, "full", 64), (10, 0.5, "scores", 64),
+                                             (5, 0.5, "scores", 192), (10, 0.5, "full", 128)])
+def test_refinement_chain_kernel_equals_the_2k_launch_path(monkeypatch, K, lam, outputs, B):
+    """bf16 mode runs the K refinement steps AND the scorer (imf_vad.py:146-150) as ONE kernel with the state on chip once a
+    micro-batch has >= 256 blocks of 64 rows (csrc/refine_chain_bf16.h): fp32 z in registers, one aliased bf16 z / h image in
+    LDS, per-wave LDS-DMA weight streams.  Same products in the same k order, same epilogue arithmetic, the scorer kernel's
+    own reduction: `fused` and `logits` must equal the 2K-launch path bit for bit (IEFVAD_NO_CHAIN=1 at model creation).
+    B = 192 with micro_batch = 128 exercises a second, smaller pass (64 chunks) through the same handle."""
+    sd = synth.make_state_dict(11, 768, 2, K)
+    img, ev = synth.make_inputs(34, B)
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    kw = dict(outputs=outputs, micro_batch=128)
+    with torch.no_grad():
+        chain = make_model(2, K, lam, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_NO_CHAIN", "1")
+        plain = make_model(2, K, lam, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+    assert set(chain) == set(plain)
+    assert torch.isfinite(plain["logits"]).all()
+    for k in chain:
+        assert torch.equal(chain[k], plain[k]), (k, (chain[k].float() - plain[k].float()).abs().max().item())
+
+
+def test_refinement_chain_kernel_propagates_non_finite_rows(monkeypatch):
+    """A NaN / inf in one snippet's fused state must stay in that row through the chain kernel exactly as through the
+    projection launches (rows are independent in imf_vad.py:146-150)."""
+    sd = synth.make_state_dict(12, 768, 2, 4)
+    img, ev = synth.make_inputs(35, 64)
+    img[3, 17, 5] = np.nan          # poisons chunk 3 through the unmasked attention
+    ev[9, 200, 700] = np.inf
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    with torch.no_grad():
+        chain = make_model(2, 4, 0.5, "StudentT", 8, sd)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_NO_CHAIN", "1")
+        plain = make_model(2, 4, 0.5, "StudentT", 8, sd)(ti, te, None, None, None)
+    for k in ("logits", "fused"):
+        a, b = chain[k].float(), plain[k].float()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), k
+        assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), k
+    bad = (~torch.isfinite(chain["logits"])).reshape(64, 256).any(dim=1).cpu().numpy()
+    assert bad[3] and bad[9] and bad.sum() == 2
+
+
 def test_xd_shaped_set_auc_and_ap_parity_bf16():
     """BASELINE config 3: XD-Violence-sized synthetic set (753 videos, ~145 k snippets), bf16 projections,
     AUC and AP (XD selects by AP, xd_train.py:114) equal to 4 d.p. against the fp32 CPU oracle."""
