@@ -55,9 +55,11 @@ GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
+PROFILE_ROUND = "r03"                                           # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
-               "bf16": "iefvad_gemm_bf16_w256_kernel (bias-type epilogues) + iefvad_gemm_bf16_pipe_kernel (refinement epilogue) "
-                       "+ iefvad_heads_fused_bf16_kernel (heads + fusion) + iefvad_outproj_ln_bf16_kernel (out_proj + LayerNorm)",
+               "bf16": "iefvad_gemm_bf16_w256_kernel (in_proj) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + "
+                       "scorer, one launch) + iefvad_heads_fused_bf16_kernel (heads + fusion) + iefvad_outproj_ln_bf16_kernel "
+                       "(out_proj + LayerNorm)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -170,11 +172,12 @@ def roofline_block(compute, stage, steps, rows_per_step):
         pure_flops = (4 * (2 * D * 3 * D) + K_STEPS * 2 * (2 * D * D)) * rows_per_step      # in_proj + refinement launches only
         pure_ms = (stage["qkv_gemm_ms"] + stage["refine_gemm_ms"]) / steps
         r["achieved_pure_projection_launches"] = pure_flops / (pure_ms * 1e-3) / 1e12
-        r["note"] = ("two of the 25 projection launches of a pass carry more than a projection and are counted whole as GEMM "
-                     "time: iefvad_heads_fused_bf16_kernel (both modalities' heads AND the precision-weighted fusion) and "
-                     "iefvad_outproj_ln_bf16_kernel (out_proj + residual + LayerNorm); the stand-alone LayerNorm / fusion "
-                     "kernels then do not run (layernorm_ms = 0).  achieved_pure_projection_launches = the same quantity over the "
-                     "22 launches that are projections only (in_proj, refinement)")
+        r["note"] = ("the 25 projections of a pass run as 6 launches: 2 x in_proj, 2 x iefvad_outproj_ln_bf16_kernel (out_proj + "
+                     "residual + LayerNorm), iefvad_heads_fused_bf16_kernel (both modalities' heads AND the precision-weighted "
+                     "fusion) and ONE iefvad_refine_chain_bf16_kernel (the 2K refinement projections and the scorer, state on "
+                     "chip); the fused launches are counted whole as GEMM time and the stand-alone LayerNorm / fusion / scorer "
+                     "kernels do not run.  achieved_pure_projection_launches = the same quantity over the in_proj and "
+                     "refinement-chain launches only")
     ppm = PRODUCTS_PER_MAC[compute]
     if ppm > 1:
         r["mfma_pipe_util"] = achieved * ppm / peak
@@ -186,16 +189,26 @@ def roofline_block(compute, stage, steps, rows_per_step):
 
 
 def traffic_from_profiles(compute, rows_per_launch):
-    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/), when they ran at this launch size."""
-    for rnd in ("r02", "r01"):
-        name = {"f32": f"{rnd}_gemm_hbm_traffic.json", "bf16x6": f"{rnd}_gemm_split_hbm_traffic.json",
-                "bf16": f"{rnd}_gemm_bf16_hbm_traffic.json"}.get(compute)
-        path = os.path.join(ROOT, "profiles", name) if name else None
-        if path and os.path.exists(path):
-            tj = json.load(open(path))
-            if tj.get("rows_per_launch") == rows_per_launch:
-                return tj["traffic_bytes_per_launch"]
-    return None
+    """HBM-side bytes per GEMM launch.  NOT measured in this run: PMC counters need their own rocprofv3 passes, so the figure
+    is read from the committed summary of such passes under profiles/ (tools/hbm_traffic.py writes it) -- and only from this
+    round's file, at this launch size, whose recorded kernel list matches the kernels this build dispatches; otherwise null.
+    Returned as an object that names its source."""
+    name = {"f32": "gemm_hbm_traffic.json", "bf16x6": "gemm_split_hbm_traffic.json", "bf16": "gemm_bf16_hbm_traffic.json"}.get(compute)
+    if not name:
+        return None
+    rel = os.path.join("profiles", f"{PROFILE_ROUND}_{name}")
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None
+    tj = json.load(open(path))
+    if tj.get("rows_per_launch") != rows_per_launch:
+        return None
+    kernels = tj.get("kernels") or ([tj["kernel"]] if "kernel" in tj else [])
+    if kernels and not all(k in GEMM_KERNEL[compute] for k in kernels):
+        return None                                  # a PMC figure of another kernel set must not sit beside fresh timings
+    return {"bytes_per_launch": tj["traffic_bytes_per_launch"], "source": rel, "measured_in_this_run": False,
+            "collected_at_head": tj.get("head"), "kernels": kernels,
+            "over_algorithmic": tj.get("traffic_over_algorithmic")}
 
 
 def run_mode(model, img, ev, steps, warmup=1):
@@ -436,15 +449,15 @@ def main():
         return (torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45,
                 torch.randn(nchunks, T, D, device=dev, generator=gen) * 0.45)
 
-    state = {"comm": None, "gather": None}
+    # how the ranks' score vectors are gathered is decided once, by all ranks together (harness.ScoreGatherer): the library's
+    # RCCL gather, or -- when a rank cannot create the communicator -- torch.distributed's all-gather; the line says which
+    gatherer = None
     if world > 1 and backend == "nccl":
-        try:
-            state["comm"] = harness.ScoreComm(dev)
-            state["gather"] = "iefvad_gather_scores (libiefvad -> librccl ncclAllGather on the forward's stream)"
-        except Exception as e:      # keep the measurement alive on RCCL through torch.distributed; say so in the line
-            state["gather"] = f"torch.distributed all_gather_into_tensor (iefvad_comm_create failed: {e})"
+        gatherer = harness.ScoreGatherer(dev)
     elif world > 1:
-        state["gather"] = "torch.distributed gloo (scores staged through the host)"
+        gatherer = harness.ScoreGatherer("cpu", prefer_library=False)
+        gatherer.label = "torch.distributed gloo (scores staged through the host)"
+    state = {"gather": gatherer.label if gatherer else None}
 
     def timed_run(img, ev, first, counts, steps, warmup):
         """Contract timing: `warmup` untimed steps, barrier + sync, exactly `steps` steps, sync + barrier, MAX over
@@ -462,17 +475,7 @@ def main():
             else:       # --plumbing-only: the global snippet indices of this rank's shard
                 scores = torch.arange(first * T, (first + counts[rank]) * T, dtype=torch.float32)
             if world > 1:
-                if state["comm"] is not None:
-                    try:
-                        scores = state["comm"].gather(scores, snips)
-                    except RuntimeError as e:     # an enqueue error is symmetric across ranks: all of them switch
-                        state["comm"] = None
-                        state["gather"] = f"torch.distributed all_gather_into_tensor (iefvad_gather_scores failed: {e})"
-                        scores = harness.gather_scores(scores, counts=snips)
-                elif backend == "nccl":
-                    scores = harness.gather_scores(scores, counts=snips)
-                else:
-                    scores = harness.gather_scores(scores.cpu(), counts=snips)
+                scores = gatherer(scores if backend == "nccl" or not gpu else scores.cpu(), snips)
             return scores
 
         for _ in range(warmup):
@@ -545,7 +548,7 @@ def main():
             line["plumbing_only"] = "no forward ran: fabricated scores, launcher / shard / gather / timing self-test"
             line["gathered_in_order"] = in_order
         if world > 1:
-            comm = state["comm"]
+            comm = gatherer.comm if gatherer is not None else None
             line["rccl_ranks"] = comm.nranks if comm is not None else (dist.get_world_size() if backend == "nccl" else 0)
             line["dist_backend"] = backend
             line["gather"] = state["gather"]
@@ -569,8 +572,8 @@ def main():
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)
-    if state["comm"] is not None:
-        state["comm"].close()
+    if gatherer is not None:
+        gatherer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

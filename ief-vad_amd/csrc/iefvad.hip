@@ -883,6 +883,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             hipEvent_t e = tm.begin(ST_REFINE);
             hipLaunchKernelGGL(iefvad_refine_chain_bf16_kernel, dim3(rows / RC_BM), dim3(64 * RC_NW), RC_LDS_BYTES, stream, ca);
             tm.end(e);
+            tm.gemm_launches += 1;
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1177,46 +1178,67 @@ extern "C" void iefvad_comm_destroy(iefvad_comm* c) {
     delete c;
 }
 
+extern "C" int32_t iefvad_rccl_version(void) {
+    const RcclApi* api = rccl_api(nullptr);
+    int v = 0;
+    if (!api || api->GetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
+
+extern "C" int iefvad_gather_plan(int32_t nranks, int32_t rank, const int64_t* counts, int64_t count, int64_t* summary,
+                                  int64_t* steps) {
+    if (!summary) return fail("iefvad_gather_plan: null summary");
+    if (!counts && count < 0) return fail("iefvad_gather_plan: count = %lld", (long long)count);
+    GatherPlan plan;
+    if (const char* why = gather_plan(nranks, rank, counts, (size_t)count, &plan)) return fail("iefvad_gather_plan: %s", why);
+    summary[0] = plan.equal ? 1 : 0;
+    summary[1] = (int64_t)plan.my_offset;
+    summary[2] = (int64_t)plan.my_count;
+    summary[3] = (int64_t)plan.total;
+    summary[4] = (int64_t)plan.steps.size();
+    if (steps)
+        for (size_t i = 0; i < plan.steps.size(); ++i) {
+            steps[4 * i + 0] = plan.steps[i].peer;
+            steps[4 * i + 1] = (int64_t)plan.steps[i].send_count;
+            steps[4 * i + 2] = (int64_t)plan.steps[i].recv_offset;
+            steps[4 * i + 3] = (int64_t)plan.steps[i].recv_count;
+        }
+    return 0;
+}
+
 extern "C" int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t count, const int64_t* counts, float* gathered,
-                                    void* stream_) {
+                                    size_t gathered_capacity, void* stream_) {
     if (!c || !gathered) return fail("iefvad_gather_scores: null argument");
     const RcclApi* api = rccl_api(nullptr);
     if (!api) return fail("iefvad_gather_scores: librccl not bound");
     hipStream_t stream = (hipStream_t)stream_;
-    bool equal = true;
-    if (counts) {
-        for (int r = 0; r < c->nranks; ++r) {
-            if (counts[r] < 0) return fail("iefvad_gather_scores: counts[%d] = %lld", r, (long long)counts[r]);
-            if (counts[r] != counts[0]) equal = false;
-        }
-        count = (size_t)counts[c->rank];
-    }
-    if (count > 0 && !local) return fail("iefvad_gather_scores: null local buffer");
-    if (equal) {   // the common case (bench, balanced shards): ONE collective
-        if (count == 0) return 0;
-        RCCL_TRY(api, api->AllGather(local, gathered, count, ncclFloat32, c->comm, stream));
+    GatherPlan plan;
+    if (const char* why = gather_plan(c->nranks, c->rank, counts, count, &plan)) return fail("iefvad_gather_scores: %s", why);
+    if (plan.total > gathered_capacity)
+        return fail("iefvad_gather_scores: the ranks contribute %zu elements, `gathered` holds %zu", plan.total, gathered_capacity);
+    if (plan.my_count > 0 && !local) return fail("iefvad_gather_scores: null local buffer");
+    // `local` may BE its own slot of `gathered` (in place, as ncclAllGather allows); any other overlap would be overwritten
+    // by a peer's slice while it is still being sent
+    if (plan.my_count > 0 && local != gathered + plan.my_offset && local < gathered + plan.total && gathered < local + plan.my_count)
+        return fail("iefvad_gather_scores: `local` overlaps `gathered` outside its own slot");
+    if (plan.total == 0) return 0;
+    if (plan.equal) {   // the common case (bench, balanced shards): ONE collective
+        RCCL_TRY(api, api->AllGather(local, gathered, plan.my_count, ncclFloat32, c->comm, stream));
         return 0;
     }
     // unequal shards: one grouped point-to-point exchange -- rank r's slice lands at its running offset on every peer
-    size_t off = 0, my_off = 0;
     RCCL_TRY(api, api->GroupStart());
     ncclResult_t first_bad = ncclSuccess;
-    for (int r = 0; r < c->nranks; ++r) {
-        const size_t n = (size_t)counts[r];
-        if (r == c->rank) {
-            my_off = off;
-        } else {
-            ncclResult_t a = count ? api->Send(local, count, ncclFloat32, r, c->comm, stream) : ncclSuccess;
-            ncclResult_t b = n ? api->Recv(gathered + off, n, ncclFloat32, r, c->comm, stream) : ncclSuccess;
-            if (first_bad == ncclSuccess) first_bad = (a != ncclSuccess) ? a : b;
-        }
-        off += n;
+    for (const GatherStep& s : plan.steps) {
+        ncclResult_t a = s.send_count ? api->Send(local, s.send_count, ncclFloat32, s.peer, c->comm, stream) : ncclSuccess;
+        ncclResult_t b = s.recv_count ? api->Recv(gathered + s.recv_offset, s.recv_count, ncclFloat32, s.peer, c->comm, stream) : ncclSuccess;
+        if (first_bad == ncclSuccess) first_bad = (a != ncclSuccess) ? a : b;
     }
     ncclResult_t ge = api->GroupEnd();      // always close the group, even after a failed enqueue
     if (first_bad != ncclSuccess) return fail("iefvad_gather_scores: %s", api->GetErrorString(first_bad));
     if (ge != ncclSuccess) return fail("iefvad_gather_scores: ncclGroupEnd: %s", api->GetErrorString(ge));
-    if (count && gathered + my_off != local)
-        HIP_TRY(hipMemcpyAsync(gathered + my_off, local, count * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (plan.my_count && gathered + plan.my_offset != local)
+        HIP_TRY(hipMemcpyAsync(gathered + plan.my_offset, local, plan.my_count * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 

@@ -727,7 +727,14 @@ class ScoreComm:
         self._last_error = _lib.last_error
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        # every failure below is made SYMMETRIC: a rank that raised alone would leave the others blocked in a collective
+        # every failure below is made SYMMETRIC: a rank that raised alone would leave the others blocked in a collective.
+        # First of all: can EVERY rank bind librccl?  (iefvad_comm_create is itself a collective -- ncclCommInitRank -- so a
+        # rank that cannot even dlopen the library must be found out before anybody enters it.)
+        ver = torch.tensor([int(self._lib.iefvad_rccl_version())], dtype=torch.int64, device=self.device)
+        dist.all_reduce(ver, op=dist.ReduceOp.MIN, group=group)
+        if int(ver.item()) <= 0:
+            raise RuntimeError("librccl cannot be bound on at least one rank (iefvad_rccl_version() == 0)")
+        self.rccl_version = int(ver.item())
         ident = [None]
         if self.rank == 0:
             buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
@@ -761,7 +768,7 @@ class ScoreComm:
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             rc = self._lib.iefvad_gather_scores(self._h, C.c_void_p(local.data_ptr()), local.numel(), carr,
-                                                C.c_void_p(out.data_ptr()), st)
+                                                C.c_void_p(out.data_ptr()), out.numel(), st)
         if rc != 0:
             raise RuntimeError("iefvad_gather_scores: " + self._last_error())
         return out
@@ -775,7 +782,8 @@ class ScoreComm:
 _score_comms: Dict[object, ScoreComm] = {}
 
 
-def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int]] = None,
+                  use_library: bool = True) -> torch.Tensor:
     """Rank-order concatenation of every rank's fp32 score vector, on every rank (= the reference's sequential
     order, test.py:123-129,153, because shards are contiguous ranges of the test list).
 
@@ -784,7 +792,8 @@ def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int
     synchronises with the host -- equal counts are ONE all-gather.  Without `counts` the lengths are exchanged first
     (one small all-gather and a host read).
     HIP tensors on an "nccl" (= RCCL) group go through the library's own `iefvad_gather_scores`; CPU tensors (the
-    gloo tests) through torch.distributed."""
+    gloo tests), and every tensor when `use_library` is False, through torch.distributed (`all_gather_into_tensor`,
+    padded to the longest shard when the counts differ)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     local = local.reshape(-1).float()
@@ -794,7 +803,7 @@ def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int
         dist.all_gather_into_tensor(allc, n, group=group)
         counts = allc.tolist()
     counts = [int(c) for c in counts]
-    if local.is_cuda and dist.get_backend(group) == "nccl":
+    if use_library and local.is_cuda and dist.get_backend(group) == "nccl":
         key = (group, local.device.index)
         if key not in _score_comms:
             _score_comms[key] = ScoreComm(local.device, group)
@@ -809,6 +818,38 @@ def gather_scores(local: torch.Tensor, group=None, counts: Optional[Sequence[int
     out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])
+
+
+class ScoreGatherer:
+    """How a multi-rank job gathers its score vectors, decided ONCE and by all ranks together: the library's RCCL gather
+    (`ScoreComm` -> `iefvad_gather_scores`) when every rank can create the communicator -- `ScoreComm.__init__` fails on
+    all ranks or on none -- else torch.distributed's `all_gather_into_tensor` (`gather_scores(use_library=False)`).
+    `label` says which one runs.  There is no switch in mid-run: an enqueue error of the library gather on one rank would
+    leave its peers inside the collective, so it propagates and ends the job instead of being papered over."""
+
+    LIB = "iefvad_gather_scores (libiefvad -> librccl: ncclAllGather, or grouped ncclSend/ncclRecv for unequal shards, on the forward's stream)"
+    TORCH = "torch.distributed all_gather_into_tensor"
+
+    def __init__(self, device, group=None, prefer_library: bool = True):
+        self.group, self.comm = group, None
+        if prefer_library:
+            try:
+                self.comm = ScoreComm(device, group)
+                self.label = self.LIB
+            except Exception as e:                  # symmetric (see ScoreComm.__init__): every rank lands here or none
+                self.label = f"{self.TORCH} (library gather unavailable: {e})"
+        else:
+            self.label = self.TORCH
+
+    def __call__(self, scores: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+        if self.comm is not None:
+            return self.comm.gather(scores, counts)
+        return gather_scores(scores, self.group, counts, use_library=False)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
 def shard_counts(lengths: Sequence[int], world: int) -> List[int]:

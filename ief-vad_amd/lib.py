@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiefvad.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
@@ -25,7 +25,7 @@ COMPUTE_CODES = {"f32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x6": COMPUTE_BF1
 SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_workspace_bytes",
            "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_last_error",
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
-           "iefvad_gather_scores"]
+           "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -114,8 +114,14 @@ def load_library() -> C.CDLL:
     lib.iefvad_comm_nranks.restype = C.c_int32
     lib.iefvad_comm_destroy.argtypes = [C.c_void_p]
     lib.iefvad_comm_destroy.restype = None
-    lib.iefvad_gather_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+    lib.iefvad_gather_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p, C.c_size_t,
+                                         C.c_void_p]
     lib.iefvad_gather_scores.restype = C.c_int
+    lib.iefvad_gather_plan.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int64)]
+    lib.iefvad_gather_plan.restype = C.c_int
+    lib.iefvad_rccl_version.argtypes = []
+    lib.iefvad_rccl_version.restype = C.c_int32
     lib.iefvad_last_error.restype = C.c_char_p
     lib.iefvad_destroy.argtypes = [C.c_void_p]
     lib.iefvad_destroy.restype = None

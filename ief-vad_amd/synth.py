@@ -103,3 +103,38 @@ def lognormal_lengths(seed: int, n_videos: int, total: int, lo: int = 16, hi: in
     x = np.clip(x / x.sum() * total, lo, hi)
     x = np.clip(np.round(x / x.sum() * total), lo, hi).astype(np.int64)
     return x
+
+
+def exact_lengths(seed: int, n_videos: int, total: int, lo: int = 4, hi: int = 400) -> np.ndarray:
+    """`lognormal_lengths` nudged so that the lengths sum to EXACTLY `total` (the longest / shortest videos absorb
+    the rounding remainder one snippet at a time, staying inside [lo, hi])."""
+    x = lognormal_lengths(seed, n_videos, total, lo, hi)
+    diff = int(total - x.sum())
+    order = np.argsort(-x, kind="stable")
+    i = 0
+    while diff != 0:
+        j = order[i % n_videos]
+        step = 1 if diff > 0 else -1
+        if lo <= x[j] + step <= hi:
+            x[j] += step
+            diff -= step
+        i += 1
+    assert int(x.sum()) == total
+    return x
+
+
+def config5_lists(golden_dir: str):
+    """BASELINE config 5 (ShanghaiTech + MSAD test lists, K = 5): the REAL frame-level ground truth and label order of
+    /root/reference/list/{shang,msad}/rgb/vitl/{gt.npy,test.csv} (fixture tests/golden/config5_gt.npz, written by
+    make_golden.py) with synthetic video lengths that sum to each gt exactly (8,723 + 9,009 = 17,732 snippets; the
+    feature files, hence the true lengths, are not in the container).
+    Returns {dataset: (lengths, labels, gt float64)} in list order."""
+    import os
+    g = np.load(os.path.join(golden_dir, "config5_gt.npz"))
+    out = {}
+    for seed, d in ((51, "shang"), (52, "msad")):
+        frames = int(g[f"{d}_frames"])
+        gt = np.unpackbits(g[f"{d}_bits"])[:frames].astype(np.float64)
+        labels = [str(x) for x in g[f"{d}_labels"]]
+        out[d] = (exact_lengths(seed, len(labels), frames // 16), labels, gt)
+    return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 2
+#define IEFVAD_ABI_VERSION 3
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -188,15 +188,29 @@ int iefvad_comm_create(const void* id_bytes, int32_t nranks, int32_t rank, iefva
 int32_t iefvad_comm_nranks(const iefvad_comm* c);
 void iefvad_comm_destroy(iefvad_comm* c);
 
+/* RCCL's own version number (ncclGetVersion) once librccl is bound, 0 when it cannot be bound in this process.  Lets every
+ * rank check -- and agree, over whatever host channel it has -- BEFORE the collective iefvad_comm_create that all ranks
+ * will get through it. */
+int32_t iefvad_rccl_version(void);
+
 /* gathered[offset(r) .. offset(r) + counts[r]) = rank r's `local[0 .. counts[r])`, for every r, on every rank;
  * offset(r) = counts[0] + ... + counts[r-1].  `local`, `gathered` are device pointers to fp32; `counts` is a HOST
  * array of nranks element counts that every rank passes identically (shards are cut from the shared, ordered test
  * list -- harness.partition_by_snippets -- so no count exchange is needed), or NULL when every rank contributes
- * `count` elements.  Equal counts run as ONE ncclAllGather; unequal counts as one grouped ncclSend/ncclRecv
- * exchange (every pair has a direct xGMI link) plus a device-to-device copy of the rank's own slice.
+ * `count` elements.  `gathered_capacity` = the number of fp32 elements `gathered` can hold; a call whose ranks
+ * contribute more fails before anything is enqueued.  `local` may be this rank's own slot of `gathered` (in place);
+ * any other overlap is an error.  Equal counts run as ONE ncclAllGather; unequal counts as one grouped
+ * ncclSend/ncclRecv exchange (every pair has a direct xGMI link) plus a device-to-device copy of the rank's own slice.
  * Enqueued on `stream` (hipStream_t); returns without synchronising. */
 int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t count, const int64_t* counts, float* gathered,
-                         void* stream);
+                         size_t gathered_capacity, void* stream);
+
+/* The exchange iefvad_gather_scores would enqueue for (nranks, rank, counts | count), as data -- host only, no GPU, no
+ * communicator: summary[0..4] = {equal counts (one all-gather) ? 1 : 0, this rank's offset, this rank's count, total
+ * elements, number of point-to-point steps}; steps[4 i ..] = {peer, elements sent to it, offset at which its slice is
+ * received, elements received}, one entry per peer in rank order (unequal counts only; `steps` may be NULL, else it holds
+ * 4 (nranks - 1) values).  Zero-length transfers are listed with count 0 and are not issued. */
+int iefvad_gather_plan(int32_t nranks, int32_t rank, const int64_t* counts, int64_t count, int64_t* summary, int64_t* steps);
 
 const char* iefvad_last_error(void);
 void iefvad_destroy(iefvad_handle* h);

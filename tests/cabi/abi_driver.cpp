@@ -103,18 +103,20 @@ int main(int argc, char** argv) {
         float* gathered = nullptr;
         HIPCK(hipMalloc((void**)&gathered, (size_t)B * T * 4));
         HIPCK(hipMemsetAsync(gathered, 0xff, (size_t)B * T * 4, stream));
-        ABICK(iefvad_gather_scores(comm, logits, (size_t)B * T, nullptr, gathered, stream));
+        ABICK(iefvad_gather_scores(comm, logits, (size_t)B * T, nullptr, gathered, (size_t)B * T, stream));
         HIPCK(hipStreamSynchronize(stream));
         std::vector<float> hg((size_t)B * T);
         HIPCK(hipMemcpy(hg.data(), gathered, hg.size() * 4, hipMemcpyDeviceToHost));
         if (memcmp(hg.data(), hl.data(), hg.size() * 4) != 0) { fprintf(stderr, "gathered scores differ from the local ones\n"); return 5; }
         const int64_t counts[1] = {(int64_t)T};          // only the first chunk's scores
         HIPCK(hipMemsetAsync(gathered, 0xff, (size_t)B * T * 4, stream));
-        ABICK(iefvad_gather_scores(comm, logits, 0, counts, gathered, stream));
+        ABICK(iefvad_gather_scores(comm, logits, 0, counts, gathered, (size_t)B * T, stream));
         HIPCK(hipStreamSynchronize(stream));
         HIPCK(hipMemcpy(hg.data(), gathered, T * 4, hipMemcpyDeviceToHost));
         if (memcmp(hg.data(), hl.data(), T * 4) != 0) { fprintf(stderr, "counted gather differs\n"); return 5; }
-        if (iefvad_gather_scores(nullptr, logits, 1, nullptr, gathered, stream) == 0) { fprintf(stderr, "null comm accepted\n"); return 5; }
+        if (iefvad_gather_scores(nullptr, logits, 1, nullptr, gathered, 1, stream) == 0) { fprintf(stderr, "null comm accepted\n"); return 5; }
+        if (iefvad_gather_scores(comm, logits, (size_t)B * T, nullptr, gathered, (size_t)B * T - 1, stream) == 0) { fprintf(stderr, "short `gathered` accepted\n"); return 5; }
+        if (iefvad_gather_scores(comm, logits, 8, nullptr, logits + 4, 8, stream) == 0) { fprintf(stderr, "overlapping buffers accepted\n"); return 5; }
         iefvad_comm_destroy(comm);
         (void)hipFree(gathered);
     }

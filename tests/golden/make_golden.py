@@ -230,7 +230,30 @@ def gen_init_checksums():
     print("wrote", path)
 
 
+def gen_config5_gt():
+    """BASELINE config 5's REAL ground truth: the two frame-level gt arrays the reference ships
+    (/root/reference/list/shang/rgb/vitl/gt.npy, 139,568 frames = 8,723 snippets; list/msad/rgb/vitl/gt.npy, 144,144
+    frames = 9,009 snippets; both float64 0/1), bit-packed, plus the label column of the two test lists
+    (list/{shang,msad}/rgb/vitl/test.csv: 197 and 241 videos, in list order).  Data only: no feature file exists for these
+    lists in the container, so the videos' lengths stay synthetic (synth.config5_lists makes them sum to the gt exactly)."""
+    out = {}
+    for d in ("shang", "msad"):
+        gt = np.load(os.path.join(REF, "list", d, "rgb", "vitl", "gt.npy"))          # allow_pickle=False (default)
+        assert gt.dtype == np.float64 and set(np.unique(gt)) <= {0.0, 1.0} and len(gt) % 16 == 0
+        out[f"{d}_bits"] = np.packbits(gt.astype(np.uint8))
+        out[f"{d}_frames"] = np.array(len(gt))
+        with open(os.path.join(REF, "list", d, "rgb", "vitl", "test.csv")) as f:
+            rows = [ln.rstrip("\n").rsplit(",", 1) for ln in f][1:]
+        out[f"{d}_labels"] = np.array([r[1] for r in rows])
+    path = os.path.join(HERE, "config5_gt.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: (v.shape if v.ndim else int(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "config5":
+        gen_config5_gt()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         gen_init_checksums()
         sys.exit(0)
@@ -246,3 +269,4 @@ if __name__ == "__main__":
     gen_harness_case()
     gen_init_checksums()
     gen_sweep_case()
+    gen_config5_gt()

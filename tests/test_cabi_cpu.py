@@ -66,8 +66,57 @@ def test_gather_entry_points_reject_bad_arguments_without_a_gpu(lib):
     assert lib.iefvad_comm_create(None, 1, 0, C.byref(h)) != 0 and "null" in L.last_error()
     assert lib.iefvad_comm_unique_id(None) != 0
     assert lib.iefvad_comm_nranks(None) == 0
-    assert lib.iefvad_gather_scores(None, None, 0, None, None, None) != 0 and "null" in L.last_error()
+    assert lib.iefvad_gather_scores(None, None, 0, None, None, 0, None) != 0 and "null" in L.last_error()
     lib.iefvad_comm_destroy(None)
+
+
+def _plan(lib, nranks, rank, counts=None, count=0):
+    carr = (C.c_int64 * nranks)(*counts) if counts is not None else None
+    summary = (C.c_int64 * 5)()
+    steps = (C.c_int64 * (4 * max(nranks - 1, 1)))()
+    assert lib.iefvad_gather_plan(nranks, rank, carr, count, summary, steps) == 0, L.last_error()
+    n = int(summary[4])
+    return dict(equal=bool(summary[0]), my_offset=int(summary[1]), my_count=int(summary[2]), total=int(summary[3]),
+                steps=[tuple(int(steps[4 * i + j]) for j in range(4)) for i in range(n)])
+
+
+def test_gather_plan_is_the_ordered_exchange(lib):
+    """The exchange `iefvad_gather_scores` enqueues, as data (`iefvad_gather_plan`: the same `gather_plan()` the gather runs
+    through), for the shard shapes `harness.partition_by_snippets` produces -- unequal counts, zero-count ranks, one rank --
+    checked on the host: no GPU and no second rank needed.  The N > 1 RCCL TRANSPORT itself has not run on hardware (a test
+    box has one GPU); what is pinned here is every (peer, offset, count) it would be given.  A simulated exchange in numpy
+    must reproduce rank-order concatenation (= the reference's sequential order, test.py:123-129,153) on every rank."""
+    import numpy as np
+    for counts in ([5, 0, 7, 3], [0, 0, 4], [1000, 1000, 1000], [9], [0, 0], [3, 3, 0, 3, 1, 2, 8, 5]):
+        n = len(counts)
+        data = [np.arange(c, dtype=np.float32) + 1000 * r for r, c in enumerate(counts)]
+        want = np.concatenate(data) if sum(counts) else np.zeros(0, np.float32)
+        plans = [_plan(lib, n, r, counts) for r in range(n)]
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        for r, p in enumerate(plans):
+            assert p["total"] == sum(counts) and p["my_count"] == counts[r] and p["my_offset"] == offs[r]
+            assert p["equal"] == (len(set(counts)) == 1)
+            got = np.full(sum(counts), -1.0, np.float32)
+            if p["equal"]:
+                assert p["steps"] == []
+                got = want.copy()                                  # one ncclAllGather: rank order by definition
+            else:
+                assert [s[0] for s in p["steps"]] == [q for q in range(n) if q != r]       # every peer once, rank order
+                for peer, send, roff, rcount in p["steps"]:
+                    assert send == counts[r] and rcount == counts[peer] and roff == offs[peer]
+                    # the peer's matching step sends exactly what this rank expects to receive
+                    back = [s for s in plans[peer]["steps"] if s[0] == r][0]
+                    assert back[1] == rcount and back[3] == send
+                    got[roff:roff + rcount] = data[peer]
+                got[p["my_offset"]:p["my_offset"] + counts[r]] = data[r]
+            assert np.array_equal(got, want), (counts, r)
+    # counts == NULL: every rank contributes `count`
+    p = _plan(lib, 4, 2, None, 250)
+    assert p == dict(equal=True, my_offset=500, my_count=250, total=1000, steps=[])
+    bad = (C.c_int64 * 2)(4, -1)
+    summary = (C.c_int64 * 5)()
+    assert lib.iefvad_gather_plan(2, 0, bad, 0, summary, None) != 0 and "negative count" in L.last_error()
+    assert lib.iefvad_gather_plan(2, 2, None, 1, summary, None) != 0 and "rank" in L.last_error()
 
 
 def test_shim_refuses_cpu_tensors():

@@ -48,6 +48,40 @@ def _worker(rank, world, port, out_path):
     # a rank with nothing to contribute
     part = torch.arange(5, dtype=torch.float32) if rank == 1 else torch.zeros(0)
     assert torch.equal(harness.gather_scores(part, counts=[0, 5][:world]), torch.arange(5, dtype=torch.float32))
+    # ScoreGatherer: the transport is chosen once, by all ranks together.  (1) the library gather cannot be set up (here:
+    # ScoreComm replaced by one that raises, as iefvad_comm_create would on a box whose librccl cannot be bound) -> the
+    # torch.distributed all-gather really runs and the label says so; (2) it can -> the library object is what is called.
+    real_comm = harness.ScoreComm
+
+    class Unavailable:
+        def __init__(self, *a, **k):
+            raise RuntimeError("librccl cannot be bound on at least one rank")
+
+    harness.ScoreComm = Unavailable
+    g = harness.ScoreGatherer("cpu")
+    assert g.comm is None and g.label.startswith(harness.ScoreGatherer.TORCH) and "librccl cannot be bound" in g.label
+    assert torch.equal(g(local, counts), full)                   # unequal counts through the padded all-gather
+    assert torch.equal(g(ramp, [1000] * world), torch.arange(world * 1000, dtype=torch.float32))
+    calls = []
+
+    class Fake:
+        def __init__(self, device, group=None):
+            self.nranks = world
+
+        def gather(self, scores, counts=None):
+            calls.append(list(counts))
+            return harness.gather_scores(scores, None, counts, use_library=False)
+
+        def close(self):
+            calls.append("closed")
+
+    harness.ScoreComm = Fake
+    g2 = harness.ScoreGatherer("cpu")
+    assert g2.label == harness.ScoreGatherer.LIB and torch.equal(g2(local, counts), full) and calls == [counts]
+    g2.close()
+    assert calls[-1] == "closed" and g2.comm is None
+    assert harness.ScoreGatherer("cpu", prefer_library=False).label == harness.ScoreGatherer.TORCH
+    harness.ScoreComm = real_comm
     if rank == 0:
         np.save(out_path, full.numpy())
         np.save(out_path + ".local0.npy", local.numpy())

@@ -193,6 +193,14 @@ def test_full_config4_batch_properties_bf16x6():
         ref = f32(img[pick].contiguous(), ev[pick].contiguous(), None, None, None)
     assert float((torch.sigmoid(ref["logits"]) - s[pick]).abs().max()) <= H.TOL_SIGMOID
     assert float((ref["logits"] - lg[pick]).abs().max()) <= H.TOL_LOGIT
+    # ... and eight of them through the CPU oracle (the fp32 restatement of the reference pinned by tests/golden), so that the
+    # bench-sized batch is checked against the reference's arithmetic and not only against another HIP mode
+    pick8 = pick[::8]
+    torch.set_num_threads(harness.host_cpu_share())
+    o = orc.forward(sd, img[pick8].cpu(), ev[pick8].cpu(), orc.OracleConfig())
+    assert float((torch.sigmoid(o["logits"]) - s[pick8].cpu()).abs().max()) <= H.TOL_SIGMOID
+    assert float((o["logits"] - lg[pick8].cpu()).abs().max()) <= H.TOL_LOGIT
+    assert float((o["w_i"].mean(-1) - out["w_i_mean"][pick8].cpu()).abs().max()) <= 1e-5
     # swap the first two 256-chunk micro-batches
     perm = torch.cat([torch.arange(256, 512), torch.arange(0, 256), torch.arange(512, 1024)]).to("cuda:0")
     with torch.no_grad():

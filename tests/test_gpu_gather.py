@@ -28,16 +28,25 @@ def test_c_abi_gather_world_of_one():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     local = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.5
     out = torch.full((4096,), -1.0, device="cuda")
-    assert lib.iefvad_gather_scores(h, local.data_ptr(), 4096, None, out.data_ptr(), st) == 0, L.last_error()
+    assert lib.iefvad_gather_scores(h, local.data_ptr(), 4096, None, out.data_ptr(), 4096, st) == 0, L.last_error()
     torch.cuda.synchronize()
     assert torch.equal(out, local)
     counts = (C.c_int64 * 1)(1000)
     out2 = torch.full((1000,), -1.0, device="cuda")
-    assert lib.iefvad_gather_scores(h, local.data_ptr(), 0, counts, out2.data_ptr(), st) == 0, L.last_error()
+    assert lib.iefvad_gather_scores(h, local.data_ptr(), 0, counts, out2.data_ptr(), 1000, st) == 0, L.last_error()
     torch.cuda.synchronize()
     assert torch.equal(out2, local[:1000])
     bad = (C.c_int64 * 1)(-3)
-    assert lib.iefvad_gather_scores(h, local.data_ptr(), 0, bad, out2.data_ptr(), st) != 0 and "counts[0]" in L.last_error()
+    assert lib.iefvad_gather_scores(h, local.data_ptr(), 0, bad, out2.data_ptr(), 1000, st) != 0 and "negative count" in L.last_error()
+    # capacity and overlap are checked before anything is enqueued
+    assert lib.iefvad_gather_scores(h, local.data_ptr(), 4096, None, out.data_ptr(), 4095, st) != 0 and "holds 4095" in L.last_error()
+    assert lib.iefvad_gather_scores(h, local.data_ptr(), 64, None, local.data_ptr() + 16, 64, st) != 0 and "overlaps" in L.last_error()
+    # in place (local IS its own slot) is what ncclAllGather allows
+    same = local.clone()
+    assert lib.iefvad_gather_scores(h, same.data_ptr(), 4096, None, same.data_ptr(), 4096, st) == 0, L.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(same, local)
+    assert lib.iefvad_rccl_version() > 0
     lib.iefvad_comm_destroy(h)
 
 

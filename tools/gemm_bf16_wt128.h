@@ -4,7 +4,7 @@
 // MFMA against 0.375), i.e. a third less LDS read traffic per FLOP, which is what the vendor library's kernels of this shape
 // do.  Same LDS images, ring protocol, k order and epilogue as iefvad_gemm_bf16_w256_kernel: bit-identical results.
 #pragma once
-#include "gemm_bf16.h"
+#include "../ief-vad_amd/csrc/gemm_bf16.h"
 
 #define GW_BM 256
 #define GW_BN 256

@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <math.h>
 #include "../ief-vad_amd/csrc/gemm_bf16.h"
-#include "../ief-vad_amd/csrc/gemm_bf16_wt128.h"
+#include "gemm_bf16_wt128.h"      // a rejected tiling kept with the tuner, not in the product
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
