@@ -25,6 +25,7 @@
 #include "heads_fused_bf16.h"
 #include "outproj_ln_bf16.h"
 #include "refine_chain_bf16.h"
+#include "ragged.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -101,6 +102,7 @@ struct iefvad_handle {
     _Float16* ref_w2h[IEFVAD_MAX_STEPS];    const float* ref_w2a[IEFVAD_MAX_STEPS];
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
+    struct MetaRing* meta;      // pinned / device metadata buffers of iefvad_forward_videos
 };
 static const int kAmaxActBase = 256;   // running-max slots of the projection matrices (multi-way words); behind them the activations'
 static int amax_act_tensors(int L, int K) { return 2 + 6 * L + 2 * K + 1; }   // inputs, per layer att|x|qkv x 2 modalities, z_0..z_K, h_0..h_{K-1}
@@ -197,6 +199,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
 
 static void release_events(iefvad_handle* h);
 static void release_graphs(iefvad_handle* h);
+static void release_meta(iefvad_handle* h);
 
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
@@ -208,6 +211,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->amax_dev) (void)hipFree(h->amax_dev);
     release_events(h);
     release_graphs(h);
+    release_meta(h);
     delete h;
 }
 
@@ -618,18 +622,24 @@ static int launch_proj(const Proj& p, int compute, bool use_split, int rows, hip
     return launch_gemm_b(g, p.nz, stream, tm, stage);
 }
 
-static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
-                        size_t workspace_bytes, const iefvad_outputs* out, hipStream_t stream, Timer& tm) {
-    if (!h || !img || !ev || !out) return fail("iefvad_forward: null argument");
-    if (!h->weights_set) return fail("iefvad_forward: weights not set");
-    if (B <= 0) return fail("iefvad_forward: B must be positive (got %d)", B);
-    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
-        return fail("iefvad_forward: unknown in_dtype %d", in_dtype);
-    if (!workspace || workspace_bytes < iefvad_workspace_bytes(h, B))
-        return fail("iefvad_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, iefvad_workspace_bytes(h, B));
-    if (((uintptr_t)workspace & 15) || ((uintptr_t)img & 15) || ((uintptr_t)ev & 15))
-        return fail("iefvad_forward: buffers must be 16-byte aligned");
+// One pass of the valid rows of whole videos (iefvad_forward_videos): where the packed rows of the pass's chunks come from and
+// where its per-row results go.
+struct RaggedPass {
+    const void* img_rows;            // first packed row of the pass, element type in_dtype
+    const void* ev_rows;
+    const RaggedChunk* d_chunks;     // device: the pass's chunks (src_row relative to the pass's first packed row)
+    const int* d_flags;              // device: NaN flag per (video, modality); nullptr = no nan_to_num
+    int valid_rows;                  // packed rows of the pass
+    float* logits;                   // packed outputs at the pass's first row, nullable
+    float* w_i_mean;
+    float* w_e_mean;
+};
 
+// One micro-batch of `nb` chunks.  Dense (rg == nullptr): pi / pe are the pass's [nb, 256, 768] blocks of `in_dtype`, results go
+// to `out` at row offset row0.  Ragged: the chunks are built on the device from rg's packed rows, everything behind the encoder
+// runs on the valid rows only, results go to rg's packed vectors (`out` must be all-null).
+static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int32_t in_dtype, int nb, size_t row0, void* workspace,
+                        const iefvad_outputs* out, const RaggedPass* rg, hipStream_t stream, Timer& tm) {
     const iefvad_config& c = h->cfg;
     const bool bf = (c.compute == IEFVAD_COMPUTE_BF16);
     const int L = c.num_layers, K = c.num_steps;
@@ -637,12 +647,9 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
     const size_t D = IEF_D;
     const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;   // imf_vad.py:134
     const float qscale = 1.0f / sqrtf((float)IEF_DH);
-
-    for (int b0 = 0; b0 < B; b0 += mb) {
-        const int nb = (B - b0 < mb) ? (B - b0) : mb;
-        const int rows = nb * IEF_T;
+    {
+        int rows = nb * IEF_T;
         const size_t R = (size_t)rows;
-        const size_t row0 = (size_t)b0 * IEF_T;
         // workspace regions, in units of R*768 floats: xin 0..2 | qkv 2..8 | att 8..10 | y 10..12 | x 12..14 | logits
         float* ws = (float*)workspace;
         float* xin[2] = {ws, ws + R * D};
@@ -653,7 +660,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         bf16_t* xb[2] = {(bf16_t*)(ws + 9 * R * D), (bf16_t*)(ws + 9 * R * D) + R * D};     // holds attb | xb
         float* ybuf[2] = {ws + 10 * R * D, ws + 11 * R * D};
         float* xbuf[2] = {ws + 12 * R * D, ws + 13 * R * D};
-        float* lg_scratch = ws + 14 * R * D;
+        float* lg_scratch = ws + 14 * R * D;          // R floats; the 3 R behind it (kWsFloatsPerRow) hold the ragged path's row means
         // tail buffers alias the (dead by then) qkv region: mu_i lv_i mu_e lv_e z | h  (bf16 mode: hb, zb in h's slot)
         float* t0 = ws + 2 * R * D;
         float* mu_i = out->image_mu ? out->image_mu + row0 * D : t0;
@@ -665,13 +672,39 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         bf16_t* hb = (bf16_t*)(t0 + 5 * R * D);
         bf16_t* zb = hb + R * D;
         float* logits = out->logits ? out->logits + row0 : lg_scratch;
+        float* wim_out = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
+        float* wem_out = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
+        if (rg) {                                     // per-row results of the pass land in scratch, then in rg's packed vectors
+            logits = lg_scratch;
+            wim_out = rg->w_i_mean ? lg_scratch + R : nullptr;
+            wem_out = rg->w_e_mean ? lg_scratch + 2 * R : nullptr;
+        }
 
         // 0. inputs: `.to(torch.float)` (imf_vad.py:41-42); bf16 mode also needs the bf16 operand copy
         const float* cur[2];
-        const size_t in_off = row0 * D * in_elem_bytes(in_dtype);
-        const char* pi = (const char*)img + in_off;
-        const char* pe = (const char*)ev + in_off;
-        if (in_dtype == IEFVAD_IN_F32) {
+        const char* pi = (const char*)pi_;
+        const char* pe = (const char*)pe_;
+        if (rg) {
+            // the chunker (tools.py:100-114) and the conditional nan_to_num (test.py:90-95) on the device: ragged.h
+            hipEvent_t e = tm.begin(ST_CAST);
+#define RAGGED_IN(T)                                                                                                        \
+    do {                                                                                                                    \
+        if (rg->d_flags)                                                                                                    \
+            hipLaunchKernelGGL(iefvad_nanflag_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,          \
+                               (const T*)rg->ev_rows, rg->d_chunks, (int*)rg->d_flags);                                     \
+        hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,         \
+                           (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], bf ? xb[0] : (bf16_t*)nullptr,  \
+                           bf ? xb[1] : (bf16_t*)nullptr);                                                                  \
+    } while (0)
+            if (in_dtype == IEFVAD_IN_F32) RAGGED_IN(float);
+            else if (in_dtype == IEFVAD_IN_F16) RAGGED_IN(__half);
+            else RAGGED_IN(__hip_bfloat16);
+#undef RAGGED_IN
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+            cur[0] = xin[0];
+            cur[1] = xin[1];
+        } else if (in_dtype == IEFVAD_IN_F32) {
             cur[0] = (const float*)pi;
             cur[1] = (const float*)pe;
             if (bf) {
@@ -807,6 +840,38 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             cur[1] = xbuf[1];
         }
 
+        // Ragged pass: everything behind the encoder is row-wise (imf_vad.py:125-150) and the reference slices the pad rows away
+        // (test.py:121), so the valid rows of the last LayerNorm's output are gathered (packed order, padded with zero rows
+        // to whole 256-row tiles) and `rows` shrinks to that count from here on.  fp16x3 keeps whole chunks: its operand
+        // scales are per chunk.  The compact operands live in the attention-output region, dead by now.
+        const float* xt[2] = {xbuf[0], xbuf[1]};      // the tail's fp32 / bf16 A operands
+        const bf16_t* xtb[2] = {xb[0], xb[1]};
+        bool compacted = false;
+        if (rg && c.compute != IEFVAD_COMPUTE_FP16X3) {
+            const int mc = (rg->valid_rows + 255) / 256 * 256;
+            if (mc < rows) {
+                CompactArgs ca;
+                memset(&ca, 0, sizeof(ca));
+                for (int m = 0; m < 2; ++m) {
+                    if (bf) { ca.xb[m] = xb[m]; ca.xcb[m] = attb[m]; xtb[m] = attb[m]; }
+                    else { ca.x[m] = xbuf[m]; ca.xc[m] = att[m]; xt[m] = att[m]; }
+                }
+                ca.chunks = rg->d_chunks;
+                const size_t tail0 = (size_t)rg->valid_rows * D, tailn = (size_t)(mc - rg->valid_rows) * D;
+                if (tailn)
+                    for (int m = 0; m < 2; ++m)
+                        HIP_TRY(bf ? hipMemsetAsync(attb[m] + tail0, 0, tailn * sizeof(bf16_t), stream)
+                                   : hipMemsetAsync(att[m] + tail0, 0, tailn * sizeof(float), stream));
+                hipEvent_t e = tm.begin(ST_CAST);
+                hipLaunchKernelGGL(iefvad_compact_rows_kernel, dim3(nb, 2), dim3(256), 0, stream, ca);
+                tm.end(e);
+                HIP_TRY(hipGetLastError());
+                rows = mc;
+                compacted = true;
+            }
+        }
+        const bool tail_split = splitmb && (!compacted || split_eligible(rows, IEF_D, IEF_D, 1));   // bf16x6: a small compact set runs on the fp32 kernels
+
         // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion, heads_fused_bf16.h.  The four
         // head tensors are stored only if the caller asked for them.
         const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= 256;
@@ -815,7 +880,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
         if (heads_fused) {
             HeadsFusedArgs ha;
             memset(&ha, 0, sizeof(ha));
-            for (int m = 0; m < 2; ++m) { ha.A[m] = xb[m]; ha.W[m] = h->head_wb[m]; ha.bias[m] = h->head_b[m]; }
+            for (int m = 0; m < 2; ++m) { ha.A[m] = xtb[m]; ha.W[m] = h->head_wb[m]; ha.bias[m] = h->head_b[m]; }
             ha.mu[0] = out->image_mu ? mu_i : nullptr;
             ha.lv[0] = out->image_logvar ? lv_i : nullptr;
             ha.mu[1] = out->event_mu ? mu_e : nullptr;
@@ -824,7 +889,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             ha.n[1] = out->w_e ? out->w_e + row0 * D : nullptr;
             ha.z = z;
             ha.zb = chain ? nullptr : zb;      // the chain kernel reads the fp32 state only
-            const bool means = out->w_i_mean || out->w_e_mean;
+            const bool means = wim_out || wem_out;
             ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 24 of its 768 floats per row
             ha.M = rows; ha.factor = factor; ha.eps = c.epsilon;
             hipEvent_t e = tm.begin(ST_HEAD);
@@ -835,7 +900,7 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             if (means) {
                 e = tm.begin(ST_FUSION);
                 hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
-                                   out->w_i_mean ? out->w_i_mean + row0 : nullptr, out->w_e_mean ? out->w_e_mean + row0 : nullptr, rows);
+                                   wim_out, wem_out, rows);
                 tm.end(e);
                 HIP_TRY(hipGetLastError());
             }
@@ -847,11 +912,11 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             memset(&p, 0, sizeof(p));
             p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
             for (int m = 0; m < 2; ++m) {
-                p.A32[m] = xbuf[m]; p.A16[m] = xb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
+                p.A32[m] = xt[m]; p.A16[m] = xtb[m]; p.W32[m] = h->head_w[m]; p.W16[m] = h->head_wb[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
                 p.Wh[m] = h->head_wh[m]; p.amaxW[m] = h->head_wa[m]; p.amaxA[m] = am_x(L - 1, m);
             }
             p.C[0] = mu_i; p.C2[0] = lv_i; p.C[1] = mu_e; p.C2[1] = lv_e;
-            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_HEAD)) return rc;
+            if (int rc = launch_proj(p, c.compute, tail_split, rows, stream, tm, ST_HEAD)) return rc;
         }
 
         // 3. precision weights + fusion (imf_vad.py:130-144), fp32 in both modes
@@ -863,8 +928,8 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             fa.n_e = out->w_e ? out->w_e + row0 * D : nullptr;
             fa.z = z;
             fa.zb = (bf && !chain) ? zb : nullptr;
-            fa.n_i_mean = out->w_i_mean ? out->w_i_mean + row0 : nullptr;
-            fa.n_e_mean = out->w_e_mean ? out->w_e_mean + row0 : nullptr;
+            fa.n_i_mean = wim_out;
+            fa.n_e_mean = wem_out;
             fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
             fa.z_amax = am_z(0);
             hipEvent_t e = tm.begin(ST_FUSION);
@@ -885,36 +950,217 @@ static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32
             tm.end(e);
             tm.gemm_launches += 1;
             HIP_TRY(hipGetLastError());
-            continue;
         }
 
         // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149); the state z stays fp32
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < K && !chain; ++k) {
             Proj p;
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
             p.A32[0] = z; p.A16[0] = zb; p.W32[0] = h->ref_w1[k]; p.W16[0] = h->ref_w1b[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k];
             p.Wh[0] = h->ref_w1h[k]; p.amaxW[0] = h->ref_w1a[k]; p.amaxA[0] = am_z(k); p.amaxC[0] = am_h(k);
             p.C[0] = bf ? nullptr : hbuf; p.Cb[0] = bf ? hb : nullptr;
-            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, tail_split, rows, stream, tm, ST_REFINE)) return rc;
             memset(&p, 0, sizeof(p));
             p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
             p.A32[0] = hbuf; p.A16[0] = hb; p.W32[0] = h->ref_w2[k]; p.W16[0] = h->ref_w2b[k]; p.Ws[0] = h->ref_w2s[k]; p.bias[0] = h->ref_b2[k];
             p.Wh[0] = h->ref_w2h[k]; p.amaxW[0] = h->ref_w2a[k]; p.amaxA[0] = am_h(k); p.amaxC[0] = am_z(k + 1);
             p.C[0] = z; p.R[0] = z; p.Cb[0] = (bf && k + 1 < K) ? zb : nullptr;
-            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
+            if (int rc = launch_proj(p, c.compute, tail_split, rows, stream, tm, ST_REFINE)) return rc;
         }
 
         // 5. scorer (imf_vad.py:150)
-        {
+        if (!chain) {
             hipEvent_t e = tm.begin(ST_SCORER);
             hipLaunchKernelGGL(iefvad_scorer_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, z,
                                h->cls_w, h->cls_b, logits, rows);
             tm.end(e);
             HIP_TRY(hipGetLastError());
         }
+
+        // ragged pass: the valid rows' results -> the caller's packed vectors (test.py:119-121: logits1[0:len_cur])
+        if (rg) {
+            hipEvent_t e = tm.begin(ST_SCORER);
+            if (compacted)
+                hipLaunchKernelGGL(iefvad_rows_out_kernel, dim3((rg->valid_rows + 255) / 256), dim3(256), 0, stream, logits, wim_out, wem_out,
+                                   rg->logits, rg->w_i_mean, rg->w_e_mean, (const RaggedChunk*)nullptr, rg->valid_rows);
+            else
+                hipLaunchKernelGGL(iefvad_rows_out_kernel, dim3(nb), dim3(256), 0, stream, logits, wim_out, wem_out, rg->logits,
+                                   rg->w_i_mean, rg->w_e_mean, rg->d_chunks, rg->valid_rows);
+            tm.end(e);
+            HIP_TRY(hipGetLastError());
+        }
     }
     return 0;
+}
+
+static int forward_impl(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, void* workspace,
+                        size_t workspace_bytes, const iefvad_outputs* out, hipStream_t stream, Timer& tm) {
+    if (!h || !img || !ev || !out) return fail("iefvad_forward: null argument");
+    if (!h->weights_set) return fail("iefvad_forward: weights not set");
+    if (B <= 0) return fail("iefvad_forward: B must be positive (got %d)", B);
+    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
+        return fail("iefvad_forward: unknown in_dtype %d", in_dtype);
+    if (!workspace || workspace_bytes < iefvad_workspace_bytes(h, B))
+        return fail("iefvad_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, iefvad_workspace_bytes(h, B));
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)img & 15) || ((uintptr_t)ev & 15))
+        return fail("iefvad_forward: buffers must be 16-byte aligned");
+    const int mb = micro_batch(h);
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = (B - b0 < mb) ? (B - b0) : mb;
+        const size_t row0 = (size_t)b0 * IEF_T;
+        const size_t in_off = row0 * IEF_D * in_elem_bytes(in_dtype);
+        if (int rc = forward_pass(h, (const char*)img + in_off, (const char*)ev + in_off, in_dtype, nb, row0, workspace, out, nullptr,
+                                  stream, tm))
+            return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole videos: valid rows in, per-snippet results out (include/iefvad.h, csrc/ragged.h)
+// ------------------------------------------------------------------------------------------------
+// chunk count of a video as the evaluation loop needs it: process_split's len // 256 + 1 chunks (tools.py:105-112) minus the
+// all-zero one of a len % 256 == 0 video, whose rows test.py:121 slices away
+static int video_chunks(int n) { return n < IEF_T ? 1 : n / IEF_T + (n % IEF_T ? 1 : 0); }
+
+// per-call metadata (chunk table, NaN flags) travels through a small ring of pinned host / device buffer pairs: the copy is
+// asynchronous, so a slot is reused only after the event recorded behind its last use has completed
+struct MetaRing {
+    static const int kSlots = 4;
+    void* host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    void* dev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[kSlots] = {0, 0, 0, 0};
+    hipEvent_t done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int turn = 0;
+};
+
+static void release_meta(iefvad_handle* h) {
+    if (!h->meta) return;
+    for (int i = 0; i < MetaRing::kSlots; ++i) {
+        if (h->meta->host[i]) (void)hipHostFree(h->meta->host[i]);
+        if (h->meta->dev[i]) (void)hipFree(h->meta->dev[i]);
+        if (h->meta->done[i]) (void)hipEventDestroy(h->meta->done[i]);
+    }
+    delete h->meta;
+    h->meta = nullptr;
+}
+
+static int videos_layout(const int32_t* lengths, int32_t nvideos, long long* total_rows, long long* total_chunks) {
+    long long rows = 0, chunks = 0;
+    for (int v = 0; v < nvideos; ++v) {
+        if (lengths[v] <= 0) return fail("iefvad_forward_videos: lengths[%d] = %d", v, lengths[v]);
+        rows += lengths[v];
+        chunks += video_chunks(lengths[v]);
+    }
+    *total_rows = rows;
+    *total_chunks = chunks;
+    return 0;
+}
+
+extern "C" size_t iefvad_videos_workspace_bytes(const iefvad_handle* h, const int32_t* lengths, int32_t nvideos) {
+    if (!h || !lengths || nvideos <= 0) return 0;
+    long long rows, chunks;
+    if (videos_layout(lengths, nvideos, &rows, &chunks) || chunks > 0x7fffffffLL) return 0;
+    return iefvad_workspace_bytes(h, (int32_t)chunks);
+}
+
+static int forward_videos_impl(iefvad_handle* h, const void* img_rows, const void* ev_rows, int32_t in_dtype, const int32_t* lengths,
+                               int32_t nvideos, int32_t nan_to_num, void* workspace, size_t workspace_bytes, float* logits,
+                               float* w_i_mean, float* w_e_mean, hipStream_t stream, Timer& tm) {
+    if (!h || !img_rows || !ev_rows || !lengths || !logits) return fail("iefvad_forward_videos: null argument");
+    if (!h->weights_set) return fail("iefvad_forward_videos: weights not set");
+    if (nvideos <= 0) return fail("iefvad_forward_videos: nvideos must be positive (got %d)", nvideos);
+    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
+        return fail("iefvad_forward_videos: unknown in_dtype %d", in_dtype);
+    long long total_rows, total_chunks;
+    if (int rc = videos_layout(lengths, nvideos, &total_rows, &total_chunks)) return rc;
+    if (total_chunks > 0x7fffffffLL / IEF_T) return fail("iefvad_forward_videos: too many chunks");
+    const size_t need = iefvad_workspace_bytes(h, (int32_t)total_chunks);
+    if (!workspace || workspace_bytes < need) return fail("iefvad_forward_videos: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)img_rows & 15) || ((uintptr_t)ev_rows & 15))
+        return fail("iefvad_forward_videos: buffers must be 16-byte aligned");
+
+    // ---- metadata: the chunk table of the whole call (src_row relative to its pass, filled below) + the flag words
+    const size_t chunk_bytes = (size_t)total_chunks * sizeof(RaggedChunk);
+    const size_t flag_off = (chunk_bytes + 255) & ~(size_t)255;
+    const size_t flag_bytes = nan_to_num ? (size_t)nvideos * 2 * sizeof(int) : 0;
+    const size_t meta_bytes = flag_off + flag_bytes;
+    if (!h->meta) {
+        h->meta = new (std::nothrow) MetaRing();
+        if (!h->meta) return fail("iefvad_forward_videos: out of host memory");
+    }
+    MetaRing& mr = *h->meta;
+    const int slot = mr.turn;
+    mr.turn = (mr.turn + 1) % MetaRing::kSlots;
+    HIP_TRY(hipSetDevice(h->device));
+    if (mr.done[slot]) HIP_TRY(hipEventSynchronize(mr.done[slot]));
+    else HIP_TRY(hipEventCreateWithFlags(&mr.done[slot], hipEventDisableTiming));
+    if (mr.cap[slot] < meta_bytes) {
+        if (mr.host[slot]) (void)hipHostFree(mr.host[slot]);
+        if (mr.dev[slot]) (void)hipFree(mr.dev[slot]);
+        mr.host[slot] = mr.dev[slot] = nullptr;
+        mr.cap[slot] = 0;
+        const size_t cap = meta_bytes * 2 + 4096;
+        HIP_TRY(hipHostMalloc(&mr.host[slot], cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&mr.dev[slot], cap));
+        mr.cap[slot] = cap;
+    }
+    RaggedChunk* hc = (RaggedChunk*)mr.host[slot];
+    const int mb = micro_batch(h);
+    {
+        // chunk table; src_row is relative to the first packed row of the chunk's PASS (passes are runs of <= mb chunks)
+        long long row = 0, pass_row0 = 0;
+        long long ci = 0;
+        for (int v = 0; v < nvideos; ++v) {
+            const int n = lengths[v], nch = video_chunks(n);
+            for (int j = 0; j < nch; ++j, ++ci) {
+                if (ci % mb == 0) pass_row0 = row;
+                const int valid = (n - j * IEF_T) < IEF_T ? (n - j * IEF_T) : IEF_T;
+                hc[ci].src_row = (int)(row - pass_row0);
+                hc[ci].valid = valid;
+                hc[ci].video = v;
+                hc[ci].pad_ = 0;
+                row += valid;
+            }
+        }
+        if (flag_bytes) memset((char*)mr.host[slot] + flag_off, 0, flag_bytes);
+    }
+    HIP_TRY(hipMemcpyAsync(mr.dev[slot], mr.host[slot], meta_bytes, hipMemcpyHostToDevice, stream));
+    const RaggedChunk* dc = (const RaggedChunk*)mr.dev[slot];
+    const int* dflags = flag_bytes ? (const int*)((const char*)mr.dev[slot] + flag_off) : nullptr;
+
+    iefvad_outputs none;
+    memset(&none, 0, sizeof(none));
+    const size_t esz = in_elem_bytes(in_dtype);
+    long long row0 = 0;
+    int rc = 0;
+    for (long long c0 = 0; c0 < total_chunks && !rc; c0 += mb) {
+        const int nb = (int)((total_chunks - c0 < mb) ? (total_chunks - c0) : mb);
+        long long vrows = 0;
+        for (int j = 0; j < nb; ++j) vrows += hc[c0 + j].valid;
+        RaggedPass rg;
+        rg.img_rows = (const char*)img_rows + (size_t)row0 * IEF_D * esz;
+        rg.ev_rows = (const char*)ev_rows + (size_t)row0 * IEF_D * esz;
+        rg.d_chunks = dc + c0;
+        rg.d_flags = dflags;
+        rg.valid_rows = (int)vrows;
+        rg.logits = logits + row0;
+        rg.w_i_mean = w_i_mean ? w_i_mean + row0 : nullptr;
+        rg.w_e_mean = w_e_mean ? w_e_mean + row0 : nullptr;
+        rc = forward_pass(h, nullptr, nullptr, in_dtype, nb, 0, workspace, &none, &rg, stream, tm);
+        row0 += vrows;
+    }
+    (void)hipEventRecord(mr.done[slot], stream);       // the slot's buffers are free once everything enqueued above has run
+    return rc;
+}
+
+extern "C" int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev_rows, int32_t in_dtype,
+                                     const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
+                                     size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream) {
+    Timer tm;
+    return forward_videos_impl(h, img_rows, ev_rows, in_dtype, lengths, nvideos, nan_to_num, workspace, workspace_bytes, logits, w_i_mean,
+                               w_e_mean, (hipStream_t)stream, tm);
 }
 
 

@@ -212,6 +212,18 @@ def _unpack_item(item, maxlen, dataset, label_map):
     return img, ev, cls, length
 
 
+def _unpack_rows(item, maxlen, dataset, label_map):
+    """One DataLoader item (batch_size=1, chunked and zero padded by the loader as the reference's is) reduced to what
+    crosses the boundary in the ragged path: views of its `length` valid rows per modality."""
+    cls = item[2][0] if isinstance(item[2], (list, tuple)) else item[2]
+    if dataset == 'xd' and label_map is not None:
+        cls = label_map[cls.split('-')[0]]            # xd_test.py:68
+    length = int(item[3])
+    img = item[0].reshape(-1, item[0].shape[-1])[:length]
+    ev = item[1].reshape(-1, item[1].shape[-1])[:length]
+    return img, ev, cls, length
+
+
 class _PinnedStager:
     """Host -> device hand-over of the evaluation loop.  The reference does `img.to(device)` on pageable tensors
     (test.py:90-95), a synchronous staged copy at a few GB/s that blocks the host for longer than a one-chunk forward
@@ -255,8 +267,78 @@ class _PinnedStager:
         return out[0], out[1]
 
 
+_copy_pool = None
+
+
+def _pool():
+    """A few host threads for the staging copies (torch's CPU copy_ and file reads release the GIL)."""
+    global _copy_pool
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(max(1, min(4, host_cpu_share())))
+    return _copy_pool
+
+
+class _RowStager:
+    """Host -> device hand-over of VALID rows (the packed evaluation loop through `MMFMIL.forward_videos`): the feature rows
+    of a batch of videos are copied, without their zero padding, into one of `slots` reusable pinned buffers -- by a few
+    threads when the batch is large -- and sent with one asynchronous copy per modality on the current stream.  Nothing on
+    the host reads the rows: the NaN scan of test.py:90-95 happens on the device (csrc/ragged.h)."""
+
+    def __init__(self, device, slots: int = 3):
+        self.device = torch.device(device)
+        self.bufs = [[None, None] for _ in range(slots)]
+        self.events = [None] * slots
+        self.turn = 0
+
+    def _buffer(self, slot, m, nbytes):
+        b = self.bufs[slot][m]
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, pin_memory=True)
+            self.bufs[slot][m] = b
+        return b
+
+    def upload(self, imgs, evs, dt):
+        """imgs / evs: per video [len, D] host tensors (views are fine).  Returns two [sum(len), D] device tensors."""
+        slot = self.turn
+        self.turn = (self.turn + 1) % len(self.bufs)
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        D = int(imgs[0].shape[1])
+        lens = [int(p.shape[0]) for p in imgs]
+        total = sum(lens)
+        esize = torch.empty(0, dtype=dt).element_size()
+        hosts = [self._buffer(slot, m, total * D * esize)[:total * D * esize].view(dt).view(total, D) for m in range(2)]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        jobs = [(hosts[m], int(offs[i]), parts[i]) for m, parts in enumerate((imgs, evs)) for i in range(len(lens))]
+
+        def run(chunk):
+            for host, off, src in chunk:
+                host[off:off + src.shape[0]].copy_(src)          # casts when the batch was widened
+
+        nbytes = 2 * total * D * esize
+        nt = 1 if nbytes < (8 << 20) else min(4, len(jobs))
+        if nt == 1:
+            run(jobs)
+        else:
+            # contiguous runs of ~equal bytes per thread
+            cuts, acc, per = [0], 0, nbytes / nt
+            for j, (_, _, src) in enumerate(jobs):
+                acc += src.shape[0] * D * esize
+                if acc >= per * len(cuts) and len(cuts) < nt:
+                    cuts.append(j + 1)
+            cuts.append(len(jobs))
+            list(_pool().map(run, [jobs[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]))
+        out = [h.to(self.device, non_blocking=True) for h in hosts]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[slot] = ev
+        return out[0], out[1]
+
+
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
-                 label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True, lanes: int = 1):
+                 label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True, lanes: int = 1,
+                 ragged: Optional[bool] = None):
     """Per-video sigmoid scores and mean fusion weights, in loader order.
 
     batch_chunks == 0: one forward per video with B = that video's chunk count -- the reference's call
@@ -264,6 +346,11 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     forward of up to `batch_chunks` chunks; legal because chunks are independent batch rows
     (imf_vad.py:115 attends within a chunk), and the trailing all-zero chunk of a len % 256 == 0 video,
     whose rows the reference slices away (test.py:121), is not computed when `skip_empty_chunks`.
+
+    `ragged` (default: whenever the model has `forward_videos`, i.e. `iefvad_amd.MMFMIL` on a HIP device, and batch_chunks > 0):
+    the packed batches go through `MMFMIL.forward_videos` -- only the VALID rows of every video are staged and uploaded, the
+    chunker, the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing run on the device, and everything behind the
+    encoder runs on the valid rows only (csrc/ragged.h).  Same scores (bit for bit in the f32 and bf16 modes).
 
     lanes > 1 (HIP devices, `iefvad_amd.MMFMIL`): consecutive forwards go round-robin to `lanes` HIP streams, each with a
     lane of the model (`MMFMIL.lanes`: same parameters, own library handle and workspace) and its own pinned staging.
@@ -284,7 +371,11 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     on_gpu = torch.device(device).type == 'cuda'
     nl = lanes if (on_gpu and lanes > 1 and hasattr(model, 'lanes')) else 1
     models = model.lanes(nl) if nl > 1 else [model]
-    stagers = [_PinnedStager(device) if on_gpu else None for _ in range(nl)]
+    if ragged is None:
+        ragged = on_gpu and batch_chunks > 0 and skip_empty_chunks and hasattr(model, 'forward_videos')
+    elif ragged and not (on_gpu and batch_chunks > 0 and hasattr(model, 'forward_videos')):
+        raise ValueError("ragged=True needs a HIP device, batch_chunks > 0 and a model with forward_videos")
+    stagers = [(_RowStager(device) if ragged else _PinnedStager(device)) if on_gpu else None for _ in range(nl)]
     streams = [torch.cuda.Stream(device=device) for _ in range(nl)] if nl > 1 else [None]
     if nl > 1:
         for s in streams:
@@ -310,6 +401,23 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         # to fp32 here rather than narrowed to the first tensor's type
         dts = {p[0].dtype for p in pend} | {p[1].dtype for p in pend}
         dt = torch.float32 if len(dts) > 1 else pend[0][0].dtype
+        if ragged:
+            if len(dts) > 1:      # a narrower video is widened at staging: its own dtype's inf -> max rule applies first (test.py:90-95)
+                pend = [tuple(torch.nan_to_num(t, nan=0.0) if (t.dtype != dt and _has_nan(t)) else t for t in (p[0], p[1])) + (p[2],)
+                        for p in pend]
+            img, ev = stager.upload([p[0] for p in pend], [p[1] for p in pend], dt)
+            lens = [n for _, _, n in pend]
+            out = model.forward_videos(img, ev, lens, nan_to_num=True)
+            dev_prob.append(out['logits'])
+            dev_wi.append(out['w_i_mean'])
+            dev_we.append(out['w_e_mean'])
+            off = total
+            for n in lens:
+                spans.append((off, n))
+                off += n
+            total = off
+            pend, pend_chunks = [], 0
+            return
         if stager is not None:
             img, ev = stager.upload([p[0] for p in pend], [p[1] for p in pend], dt)
         else:
@@ -334,6 +442,14 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
 
     with torch.no_grad():
         for item in test_loader:
+            if ragged:
+                img, ev, cls, n = _unpack_rows(item, maxlen, dataset, label_map)
+                classes.append(cls)
+                pend.append((img, ev, n))
+                pend_chunks += n // maxlen + (1 if n % maxlen else 0) if n >= maxlen else 1
+                if pend_chunks >= batch_chunks:
+                    flush()
+                continue
             img, ev, cls, n = _unpack_item(item, maxlen, dataset, label_map)
             classes.append(cls)
             if batch_chunks > 0 and skip_empty_chunks and n >= maxlen and n % maxlen == 0:
@@ -370,10 +486,13 @@ class FeatureFilePipeline:
     away by test.py:121)."""
 
     def __init__(self, paths: Sequence[str], labels: Sequence[str], clip_dim: int, event_dir: str, device,
-                 batch_chunks: int = 64, workers: int = 2, prefetch: int = 2):
+                 batch_chunks: int = 64, workers: int = 2, prefetch: int = 2, ragged: bool = False):
         self.paths, self.labels = list(paths), list(labels)
         self.clip_dim, self.event_dir, self.device = clip_dim, event_dir, torch.device(device)
         self.batch_chunks, self.workers, self.prefetch = batch_chunks, workers, max(1, prefetch)
+        # ragged: batches are the videos' VALID rows only, [sum(len), D] per modality, for `MMFMIL.forward_videos`; no zero
+        # padding is written and nothing on the host scans the payload (the NaN rule of test.py:90-95 runs on the device)
+        self.ragged = ragged
 
     @staticmethod
     def _header(path):
@@ -396,7 +515,7 @@ class FeatureFilePipeline:
         return (p,) + hi, (pe,) + he
 
     @staticmethod
-    def _fill(dst: np.ndarray, src):
+    def _fill(dst: np.ndarray, src, scan: bool = True):
         """One read() of the payload from the page cache straight into the pinned staging rows (no intermediate
         array, no page faults of a memory map); a dtype mismatch (mixed-dtype batch) goes through a temporary."""
         path, shape, dtype, offset = src
@@ -409,15 +528,17 @@ class FeatureFilePipeline:
             else:
                 tmp = np.fromfile(f, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
                 np.copyto(dst, tmp, casting='unsafe')
+        if not scan and dtype == dst.dtype:
+            return            # ragged path, payload in its own dtype: the device decides (csrc/ragged.h)
         if np.issubdtype(dst.dtype, np.floating) and np.isnan(np.sum(dst, dtype=np.float32)) and np.isnan(dst).any():
             # conditional nan_to_num (test.py:90-95): NaN -> 0, +-inf -> the SOURCE dtype's max / min
             fi = np.finfo(dtype)
             np.nan_to_num(dst, copy=False, nan=0.0, posinf=float(fi.max), neginf=float(fi.min))
 
     @classmethod
-    def _fill_many(cls, jobs):
+    def _fill_many(cls, jobs, scan: bool = True):
         for dst, src in jobs:
-            cls._fill(dst, src)
+            cls._fill(dst, src, scan)
 
     def batches(self):
         """Yields (img [B,T,D] device tensor, ev, [(video index, n snippets, n chunks), ...])."""
@@ -445,6 +566,18 @@ class FeatureFilePipeline:
                 D = int(maps[plan[0][0]][0][1][1])
                 nchunks = sum(nch for _, _, nch in plan)
                 tdt = torch.from_numpy(np.zeros(0, dt)).dtype
+                if self.ragged:
+                    nrows = sum(n for _, n, _ in plan)
+                    hi = torch.empty(nrows, D, dtype=tdt, pin_memory=pin)
+                    he = torch.empty(nrows, D, dtype=tdt, pin_memory=pin)
+                    ni, ne = hi.numpy(), he.numpy()
+                    jobs, off = [], 0
+                    for idx, n, nch in plan:
+                        jobs.append((ni[off:off + n], maps[idx][0]))
+                        jobs.append((ne[off:off + n], maps[idx][1]))
+                        off += n
+                    nt = max(1, min(self.workers, len(jobs)))
+                    return hi, he, [pool.submit(self._fill_many, jobs[w::nt], False) for w in range(nt)], plan
                 hi = torch.empty(nchunks, T, D, dtype=tdt, pin_memory=pin)
                 he = torch.empty(nchunks, T, D, dtype=tdt, pin_memory=pin)
                 ni, ne = hi.numpy().reshape(-1, D), he.numpy().reshape(-1, D)
@@ -496,18 +629,26 @@ def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch
     with open(args.test_list, newline='') as f:
         rows = list(csv.DictReader(f))
     paths, labels = [r['path'] for r in rows], [r['label'] for r in rows]
-    pipe = FeatureFilePipeline(paths, labels, args.visual_length, EVENT_DIR[dataset], device, batch_chunks, workers)
+    ragged = torch.device(device).type == 'cuda' and hasattr(model, 'forward_videos')
+    pipe = FeatureFilePipeline(paths, labels, args.visual_length, EVENT_DIR[dataset], device, batch_chunks, workers,
+                               ragged=ragged)
     model.eval()
     t0 = time.perf_counter()
     outs, metas = [], []
     with torch.no_grad():
         for img, ev, meta in pipe.batches():
-            o = model(img, ev, None, None, None)
-            outs.append(o['logits'].reshape(img.shape[0], -1))
+            if ragged:       # valid rows only; chunker, NaN rule and [0:len] slicing on the device (csrc/ragged.h)
+                outs.append(model.forward_videos(img, ev, [n for _, n, _ in meta])['logits'])
+            else:
+                o = model(img, ev, None, None, None)
+                outs.append(o['logits'].reshape(img.shape[0], -1))
             metas.append(meta)
     T = args.visual_length
     pieces = []
     for lg, meta in zip(outs, metas):
+        if ragged:
+            pieces.append(lg)
+            continue
         off = 0
         for _, n, nch in meta:
             pieces.append(lg[off:off + nch].reshape(-1)[:n])

@@ -338,3 +338,48 @@ class MMFMIL(nn.Module):
         if self.outputs == "full":
             return {k: res[k] for k in OUTPUT_KEYS}   # the reference's key order
         return res
+
+    def forward_videos(self, img_rows: torch.Tensor, ev_rows: torch.Tensor, lengths, nan_to_num: bool = True
+                       ) -> Dict[str, torch.Tensor]:
+        """Scores of whole videos (`iefvad_forward_videos`, include/iefvad.h): `img_rows`, `ev_rows` are the videos' VALID
+        feature rows concatenated in list order, [sum(lengths), D] on the device; `lengths` the snippets per video.  The
+        chunker (tools.py:100-114), the conditional nan_to_num of test.py:90-95 and the `[0:len]` slicing of
+        test.py:119-121,131-138 happen on the device.  Returns `logits`, `w_i_mean`, `w_e_mean`, each [sum(lengths)]."""
+        if self.training:
+            raise RuntimeError("iefvad_amd.MMFMIL is inference-only; call model.eval() first")
+        self._noise_code()
+        if not (img_rows.is_cuda and ev_rows.is_cuda):
+            raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback")
+        lens = [int(n) for n in lengths]
+        total = sum(lens)
+        D = self.temporal.embed_dim
+        if img_rows.shape != ev_rows.shape or img_rows.dim() != 2 or tuple(img_rows.shape) != (total, D):
+            raise ValueError(f"expected two [{total}, {D}] tensors (sum of lengths x D), got {tuple(img_rows.shape)} and "
+                             f"{tuple(ev_rows.shape)}")
+        if not lens or min(lens) < 1:
+            raise ValueError("every video needs at least one snippet")
+        device = img_rows.device
+        img = self._prepare_input(img_rows)
+        ev = self._prepare_input(ev_rows)
+        if ev.dtype != img.dtype:
+            img, ev = img.to(torch.float), ev.to(torch.float)
+        lib = _lib.load_library()
+        larr = (C.c_int32 * len(lens))(*lens)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            self._ensure_handle(device)
+            self._ensure_weights(device, stream)
+            need = lib.iefvad_videos_workspace_bytes(self._handle, larr, len(lens))
+            if self._workspace is None or self._workspace.device != device or self._workspace.numel() < need:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+            f32 = dict(dtype=torch.float32, device=device)
+            res = {"logits": torch.empty(total, **f32), "w_i_mean": torch.empty(total, **f32), "w_e_mean": torch.empty(total, **f32)}
+            rc = lib.iefvad_forward_videos(self._handle, C.c_void_p(img.data_ptr()), C.c_void_p(ev.data_ptr()),
+                                           _IN_DTYPES[img.dtype], larr, len(lens), 1 if nan_to_num else 0,
+                                           C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(),
+                                           C.c_void_p(res["logits"].data_ptr()), C.c_void_p(res["w_i_mean"].data_ptr()),
+                                           C.c_void_p(res["w_e_mean"].data_ptr()), C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError("iefvad_forward_videos: " + _lib.last_error())
+        return res

@@ -155,6 +155,28 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
                          void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream,
                          iefvad_stage_times* times);
 
+/* ---- whole videos --------------------------------------------------------------------------------------------------
+ * The hot loop of the reference's evaluation, one level up from the forward: for every video the loader pads the [len, D]
+ * feature files to whole T = 256 chunks on the host (process_split, /root/reference/data/tools.py:100-114; dataset.py:34-52),
+ * test() scans the padded tensors for NaN and replaces them (`if torch.isnan(x).any(): x = torch.nan_to_num(x, nan=0.0)`,
+ * /root/reference/test.py:90-95), runs the model on every chunk row and keeps `logits.reshape(-1)[0:len]`
+ * (test.py:119-121) and the first len row means of w_i / w_e (test.py:131-138).  iefvad_forward_videos does exactly that
+ * for a batch of videos with only the VALID rows crossing the boundary:
+ *   img_rows, ev_rows   device, [sum(lengths), D] of `in_dtype`: the videos' feature rows concatenated in list order (no padding)
+ *   lengths             HOST array of nvideos snippet counts (>= 1)
+ *   nan_to_num          non-zero: the conditional replacement above, decided per video and per modality on the device
+ *                       (NaN -> 0, +-inf -> the largest / smallest finite value of `in_dtype`); zero: rows are used as they are
+ *   logits, w_i_mean, w_e_mean   device, [sum(lengths)] fp32 each, the means nullable: per-snippet results in the same order
+ * Chunks are laid out on the device (zero padded; the all-zero chunk that process_split appends to a len % 256 == 0 video,
+ * whose rows test.py:121 slices away, is not built), the encoder runs on whole chunks (attention is unmasked over the padded
+ * window, as in the reference), and everything behind the encoder -- row-wise in the reference, imf_vad.py:125-150 -- runs on
+ * the valid rows only.  Results equal those of iefvad_forward on the host-padded chunks (bit for bit in the F32 and BF16 modes).
+ * Workspace: iefvad_videos_workspace_bytes.  Enqueued on `stream`; `lengths` is consumed before the call returns. */
+size_t iefvad_videos_workspace_bytes(const iefvad_handle* h, const int32_t* lengths, int32_t nvideos);
+int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev_rows, int32_t in_dtype,
+                          const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
+                          size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
+
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
  * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);

@@ -1,0 +1,141 @@
+"""`iefvad_forward_videos` (include/iefvad.h, csrc/ragged.h): whole videos cross the boundary as their VALID rows; the
+chunker (tools.py:100-114), the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing (test.py:119-121,131-138)
+run on the device and everything behind the encoder runs on the valid rows only.  Checked against the reference-shaped
+route: host-side process_split + `_unpack_item` + the dense forward on zero-padded chunks, which the capture tests pin to the
+reference's own test()."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import iefvad_amd
+from iefvad_amd import harness, synth
+from oracle import iefvad_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+EDGE_LENGTHS = [37, 255, 256, 257, 512, 1500, 1, 300, 64, 768]      # SURVEY 8d config 1's chunk-edge cases and then some
+
+
+def make_model(compute, L=2, K=3, **kw):
+    sd = synth.make_state_dict(41, 768, L, K)
+    args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5, noise_model="StudentT", nu=8)
+    m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, compute=compute, **kw)
+    m.load_state_dict(sd)
+    return m.to("cuda:0").eval(), sd
+
+
+def videos(lengths, seed=6, dtype=np.float32):
+    return [synth.make_video(seed, i, int(n), dtype=dtype) for i, n in enumerate(lengths)]
+
+
+def dense_reference(model, vids):
+    """The reference-shaped route: zero-padded chunks of every video in one dense forward, then [0:len] per video."""
+    ci = [harness.process_split(v[0], 256)[0].reshape(-1, 256, 768) for v in vids]
+    ce = [harness.process_split(v[1], 256)[0].reshape(-1, 256, 768) for v in vids]
+    img = torch.from_numpy(np.concatenate(ci)).cuda()
+    ev = torch.from_numpy(np.concatenate(ce)).cuda()
+    with torch.no_grad():
+        out = model(img, ev, None, None, None)
+    lg, wi, we = out["logits"].reshape(-1), out["w_i_mean"].reshape(-1), out["w_e_mean"].reshape(-1)
+    res, off = {"logits": [], "w_i_mean": [], "w_e_mean": []}, 0
+    for v, c in zip(vids, ci):
+        n = v[0].shape[0]
+        for k, t in (("logits", lg), ("w_i_mean", wi), ("w_e_mean", we)):
+            res[k].append(t[off:off + n])
+        off += c.shape[0] * 256
+    return {k: torch.cat(v) for k, v in res.items()}
+
+
+def ragged(model, vids, **kw):
+    img = torch.from_numpy(np.concatenate([v[0] for v in vids])).cuda()
+    ev = torch.from_numpy(np.concatenate([v[1] for v in vids])).cuda()
+    with torch.no_grad():
+        return model.forward_videos(img, ev, [v[0].shape[0] for v in vids], **kw)
+
+
+@pytest.mark.parametrize("compute,micro_batch", [("f32", 0), ("f32", 3), ("bf16", 0), ("bf16", 5), ("fp16x3", 0)])
+def test_forward_videos_is_bit_identical_to_the_padded_forward(compute, micro_batch):
+    """Chunk-edge lengths (len < 256, == 255 / 256 / 257, multiples of 256, a one-snippet video, a six-chunk video); with a
+    small micro-batch the call runs as several passes, each compacting its own valid rows."""
+    model, _ = make_model(compute, outputs="scores", micro_batch=micro_batch)
+    vids = videos(EDGE_LENGTHS)
+    want = dense_reference(model, vids)
+    got = ragged(model, vids)
+    for k in want:
+        assert got[k].shape == want[k].shape == (sum(EDGE_LENGTHS),)
+        assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+
+
+def test_forward_videos_large_batch_bf16_kernels_and_bf16x6_tolerance():
+    """A list large enough for the full-grid bf16 kernels on BOTH sides of the compaction (fused out_proj + LayerNorm, fused
+    heads + fusion, the refinement chain): still bit-identical, although the tail now runs on ~60 % of the rows.  bf16x6: the
+    compact tail may run on other tilings than the dense one (same arithmetic, fp32-accurate): fp32 gates."""
+    lengths = synth.lognormal_lengths(8, 420, 60000, lo=16, hi=3000)
+    vids = videos(lengths, seed=8)
+    model, sd = make_model("bf16", K=10, outputs="scores")
+    want, got = dense_reference(model, vids), ragged(model, vids)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    del model
+    model, _ = make_model("bf16x6", K=10, outputs="scores")
+    want, got = dense_reference(model, vids), ragged(model, vids)
+    assert float((torch.sigmoid(got["logits"]) - torch.sigmoid(want["logits"])).abs().max()) <= H.TOL_SIGMOID
+    assert float((got["logits"] - want["logits"]).abs().max()) <= H.TOL_LOGIT
+    assert float((got["w_i_mean"] - want["w_i_mean"]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_forward_videos_nan_rule_matches_the_host_rule(dtype):
+    """test.py:90-95: `if torch.isnan(x).any(): x = torch.nan_to_num(x, nan=0.0)` per video and modality -- NaN -> 0 and, only in
+    that case, +-inf -> the dtype's max / min.  Video 1: NaN + inf in the image features; video 3: inf only (no replacement: the
+    chunk's scores go NaN, as in the reference); video 4: NaN in the event features of its second chunk.  Compared with the
+    host rule (`harness._unpack_item`) followed by the dense forward, bit for bit including the NaN pattern."""
+    lengths = [100, 300, 50, 80, 600, 256]
+    vids = videos(lengths, seed=9, dtype=dtype)
+    vids[1][0][7, 5] = np.nan
+    vids[1][0][290, 100] = np.inf
+    vids[1][0][3, 9] = -np.inf
+    vids[3][0][10, 10] = np.inf
+    vids[4][1][400, 767] = np.nan
+    model, _ = make_model("f32", outputs="scores")
+
+    def items():
+        for img, ev in vids:
+            ci, n = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
+
+    host, _, wi_h, _ = harness.score_loader(model, items(), 256, "cuda:0", "ucfcrime", batch_chunks=4, ragged=False)
+    dev, _, wi_d, _ = harness.score_loader(model, items(), 256, "cuda:0", "ucfcrime", batch_chunks=4, ragged=True)
+    for i, (a, b) in enumerate(zip(host, dev)):
+        assert np.array_equal(np.isnan(a), np.isnan(b)), i
+        assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0)), i
+    for a, b in zip(wi_h, wi_d):
+        assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
+    assert np.isfinite(dev[1]).all() and np.isfinite(dev[4]).all()            # replaced
+    assert np.isnan(dev[3]).all()                                             # inf without NaN: left alone, poisons its chunk
+    assert all(np.isfinite(dev[i]).all() for i in (0, 2, 5))
+    # nan_to_num=False: rows are used as they are
+    raw = ragged(model, vids, nan_to_num=False)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    lg = raw["logits"].cpu().numpy()
+    assert np.isnan(lg[off[1]:off[2]]).all() and np.isfinite(lg[off[0]:off[1]]).all()
+
+
+def test_forward_videos_matches_the_oracle_and_rejects_bad_arguments():
+    model, sd = make_model("f32", outputs="scores")
+    vids = videos([90, 257, 30], seed=10)
+    got = ragged(model, vids)
+    torch.set_num_threads(harness.host_cpu_share())
+    want = np.concatenate(orc.score_videos(orc.OracleMMFMIL(sd, orc.OracleConfig(num_refinement_steps=3)), vids))
+    assert np.abs(torch.sigmoid(got["logits"]).cpu().numpy() - want).max() <= H.TOL_SIGMOID
+    img = torch.zeros(10, 768, device="cuda")
+    with pytest.raises(ValueError, match="sum of lengths"):
+        model.forward_videos(img, img, [4, 5])
+    with pytest.raises(ValueError, match="at least one snippet"):
+        model.forward_videos(img, img, [10, 0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.forward_videos(img.cpu(), img.cpu(), [10])
