@@ -299,8 +299,9 @@ def ucf_eval(sd, margs, dev, a):
                         "ano_auc": res["ano_auc"],
                         "pattern": ("one forward per video (test.py:76-117)" + (f", consecutive videos on {lanes} HIP streams "
                                     "(same kernels, bit-identical scores)" if lanes > 1 else "")) if bc == 0 else
-                                   f"chunks of consecutive videos packed into forwards of >= {bc} chunks, forwards "
-                                   f"round-robin on {lanes} HIP streams (H2D of one overlaps the forward of another)"}
+                                   f"valid rows of consecutive videos packed into iefvad_forward_videos calls of >= {bc} chunks "
+                                   f"(chunker, NaN rule and [0:len] slicing on the device, tail on the valid rows), calls "
+                                   f"round-robin on {lanes} HIP streams (staging + H2D of one overlaps the forward of another)"}
         if "per_video_4lanes_f32" in results and compute == "f32":
             out["per_video_4lanes_f32"]["bit_identical_to_per_video_f32"] = bool(all(
                 np.array_equal(x, y) for x, y in zip(results["per_video_4lanes_f32"], results["per_video_f32"])))
@@ -331,65 +332,95 @@ def ucf_eval(sd, margs, dev, a):
     return out
 
 
-def dataset_eval(tag, dataset, nvid, total_target, seed, wseed, K, compute, dev, a, lo=16, hi=8000, batch_chunks=256,
-                 normal_keys=("Normal",)):
-    """One of BASELINE's dataset-shaped configs (3: XD-Violence-sized, bf16; 5: ShanghaiTech + MSAD sized, K = 5, bf16) through
-    the evaluation loop: synthetic features of the set's size held in host memory, chunks packed across videos, wall clock
-    including the H2D copies; AUC / AP / Ano-AUC against the fp32 CPU oracle on a bounded prefix of the same list."""
+def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=2):
+    """One of BASELINE's dataset-shaped configs (3: XD-Violence-sized, bf16; 5: the ShanghaiTech + MSAD test lists with their
+    real ground truth, K = 5, bf16) through the evaluation loop.  `parts` = [(dataset, lengths, classes, gt, seed, normal_keys)]:
+    one or more test lists scored in ONE packed pass over the same weights (synthetic features of the lists' sizes held in host
+    memory as a DataLoader would deliver them: chunked and zero padded by process_split); the wall clock covers everything
+    from those host tensors to the ordered score vectors (staging of the valid rows, H2D, `iefvad_forward_videos`, D2H).
+    Metrics per list; scores / AUC / AP against the fp32 CPU oracle on a time-bounded, evenly spread sample of the videos."""
     import numpy as np
     import torch
     from iefvad_amd import harness, synth
     from oracle import iefvad_oracle as orc
-    lengths = synth.lognormal_lengths(seed, nvid, total_target, lo=lo, hi=hi)
-    keys = harness.CLASS_KEYS[dataset]
-    classes = [keys[i % len(keys)] for i in range(nvid)]
-    total = int(lengths.sum())
-    gt = synth.make_gt(seed, total)
-    items = []
-    for i, n in enumerate(lengths):
-        img, ev = synth.make_video(seed, i, int(n))
-        ci, _ = harness.process_split(img, T)
-        ce, _ = harness.process_split(ev, T)
-        items.append((torch.from_numpy(ci).unsqueeze(0), torch.from_numpy(ce).unsqueeze(0), (classes[i],), torch.tensor([int(n)])))
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    items, bounds = [], []
+    for dataset, lengths, classes, gt, seed, normal_keys in parts:
+        lo_i = len(items)
+        for i, n in enumerate(lengths):
+            img, ev = synth.make_video(seed, i, int(n))
+            ci, _ = harness.process_split(img, T)
+            ce, _ = harness.process_split(ev, T)
+            items.append((torch.from_numpy(ci).unsqueeze(0), torch.from_numpy(ce).unsqueeze(0), (classes[i],), torch.tensor([int(n)])))
+        bounds.append((lo_i, len(items)))
+    nvid = len(items)
+    total = int(sum(int(np.sum(p[1])) for p in parts))
     margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K, lambda_ref=0.5, noise_model="StudentT", nu=8)
     sd = synth.make_state_dict(wseed, D, L, K)
     model = make_model(sd, margs, dev, a, compute, outputs="scores")
-    harness.score_loader(model, items, T, dev, dataset, batch_chunks=batch_chunks, lanes=3)          # warm-up: every lane
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    scores, cls, _, _ = harness.score_loader(model, items, T, dev, dataset, batch_chunks=batch_chunks, lanes=3)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    res = harness.evaluate_scores(scores, cls, gt, dataset, verbose=False, normal_keys=normal_keys)
-    out = {"workload": f"{tag}: synthetic {dataset}-shaped test set, {nvid} videos, {total} snippets, K={K}, projections={compute}, "
-                       f"chunks of consecutive videos packed into forwards of >= {batch_chunks}, forwards round-robin on 3 HIP streams",
-           "videos": nvid, "snippets": total, "compute": compute, "snippets_per_s": total / dt, "seconds": dt,
-           "auc": res["roc"], "ap": res["ap"], "ano_auc": res["ano_auc"]}
-    del model
-    # fp32 CPU oracle on a prefix of the list that covers every class key (the metric tail needs them all), bounded in time
     torch.set_num_threads(host_cpu_share())
+    harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)          # warm-up: every lane
+    torch.cuda.synchronize()
+    dts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        scores, cls, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[1]                                # median of three passes
+    chunks = sum((int(n) // T + (1 if int(n) % T else 0)) if int(n) >= T else 1 for p in parts for n in p[1])
+    out = {"workload": f"{tag}: {' + '.join(p[0] for p in parts)} test list(s), {nvid} videos, {total} snippets ({chunks} chunks = "
+                       f"{chunks * T} chunk rows), K={K}, projections={compute}; valid rows of consecutive videos packed into "
+                       f"iefvad_forward_videos calls of >= {batch_chunks} chunks, round-robin on {lanes} HIP streams",
+           "videos": nvid, "snippets": total, "chunk_rows": chunks * T, "compute": compute, "snippets_per_s": total / dt,
+           "seconds": dt, "seconds_all_passes": dts, "lists": {}}
+    for (dataset, lengths, classes, gt, seed, normal_keys), (lo_i, hi_i) in zip(parts, bounds):
+        res = harness.evaluate_scores(scores[lo_i:hi_i], classes, gt, dataset, verbose=False, normal_keys=normal_keys)
+        out["lists"][dataset] = {"videos": hi_i - lo_i, "snippets": int(np.sum(lengths)), "auc": res["roc"], "ap": res["ap"],
+                                 "ano_auc": res["ano_auc"], "gt_positive_fraction": float(np.mean(gt))}
+    del model
+    # fp32 CPU oracle on an evenly spread sample of the videos, bounded in time
     oracle = orc.OracleMMFMIL(sd, orc.OracleConfig(num_layers=L, num_refinement_steps=K, nu=8))
+    offs = np.concatenate([[0], np.cumsum([len(s_) for s_ in scores])])
+    gt_all = np.concatenate([p[3] for p in parts])
+    order = list(range(0, nvid, 7)) + [i for i in range(nvid) if i % 7]
     t0 = time.perf_counter()
-    cpu_scores = []
-    step = 8
-    for lo_i in range(0, nvid, step):
-        sc, _, _, _ = harness.score_loader(oracle, items[lo_i:lo_i + step], T, "cpu", dataset, batch_chunks=8)
+    picked, cpu_scores = [], []
+    for lo_i in range(0, len(order), 8):
+        idx = order[lo_i:lo_i + 8]
+        sc, _, _, _ = harness.score_loader(oracle, [items[i] for i in idx], T, "cpu", "ucfcrime", batch_chunks=8)
+        picked += idx
         cpu_scores += sc
-        if time.perf_counter() - t0 > a.cpu_seconds and len(cpu_scores) >= 4 * len(keys):
+        if time.perf_counter() - t0 > a.cpu_seconds and len(picked) >= 32:
             break
     t_cpu = time.perf_counter() - t0
-    nv = len(cpu_scores)
     nsub = int(sum(len(x) for x in cpu_scores))
-    gt_sub = gt[:16 * nsub]
-    r_cpu = harness.evaluate_scores(cpu_scores, classes[:nv], gt_sub, dataset, verbose=False, normal_keys=normal_keys)
-    r_gpu = harness.evaluate_scores(scores[:nv], classes[:nv], gt_sub, dataset, verbose=False, normal_keys=normal_keys)
+    g_cat = np.concatenate([scores[i] for i in picked])
+    c_cat = np.concatenate(cpu_scores)
+    gt_sub = np.concatenate([gt_all[16 * offs[i]:16 * offs[i + 1]] for i in picked])
     out["vs_fp32_cpu_oracle_on_sample"] = {
-        "videos": nv, "snippets": nsub, "oracle_snippets_per_s": nsub / t_cpu, "cores": torch.get_num_threads(),
-        "max_abs_score_diff": float(np.abs(np.concatenate(scores[:nv]) - np.concatenate(cpu_scores)).max()),
-        "abs_auc_diff": abs(r_gpu["roc"] - r_cpu["roc"]), "abs_ap_diff": abs(r_gpu["ap"] - r_cpu["ap"]),
-        "abs_ano_auc_diff": abs(r_gpu["ano_auc"] - r_cpu["ano_auc"])}
+        "videos": len(picked), "snippets": nsub, "oracle_snippets_per_s": nsub / t_cpu, "cores": torch.get_num_threads(),
+        "max_abs_score_diff": float(np.abs(g_cat - c_cat).max()),
+        "abs_auc_diff": abs(roc_auc_score(gt_sub, np.repeat(g_cat, 16)) - roc_auc_score(gt_sub, np.repeat(c_cat, 16))),
+        "abs_ap_diff": abs(average_precision_score(gt_sub, np.repeat(g_cat, 16)) - average_precision_score(gt_sub, np.repeat(c_cat, 16)))}
     out["x_cpu_oracle"] = out["snippets_per_s"] / (nsub / t_cpu)
     return out
+
+
+def xd_parts():
+    from iefvad_amd import harness, synth
+    lengths = synth.lognormal_lengths(2, 753, 145000)
+    keys = harness.CLASS_KEYS["xd"]
+    classes = [keys[i % len(keys)] for i in range(753)]
+    return [("xd", lengths, classes, synth.make_gt(2, int(lengths.sum())), 2, ("normal",))]
+
+
+def config5_parts():
+    """The ShanghaiTech and MSAD test lists: real frame-level gt and label order (tests/golden/config5_gt.npz), synthetic
+    features whose lengths sum to each gt exactly (8,723 + 9,009 = 17,732 snippets)."""
+    from iefvad_amd import synth
+    lists = synth.config5_lists(os.path.join(ROOT, "tests", "golden"))
+    return [(d, lists[d][0], lists[d][1], lists[d][2], seed, nk) for seed, d, nk in ((51, "shang", ("normal",)), (52, "msad", ("Normal",)))]
 
 
 def main():
@@ -565,10 +596,10 @@ def main():
             torch.cuda.empty_cache()
             line["ucf_eval"] = ucf_eval(sd, margs, dev, a)
             # BASELINE configs 3 and 5 (bf16 projections, fp32 state), bounded: driver-side records of what tests/test_gpu_bf16.py gates
-            line["xd_eval"] = dataset_eval("BASELINE config 3", "xd", 753, 145000, 2, 17, 10, "bf16", dev, a, batch_chunks=128,
-                                           normal_keys=("normal",))
-            line["shang_msad_eval"] = dataset_eval("BASELINE config 5", "msad", 438, 17732, 5, 19, 5, "bf16", dev, a, lo=4, hi=400,
-                                                   batch_chunks=32)
+            line["xd_eval"] = dataset_eval("BASELINE config 3 (synthetic XD-Violence-sized set)", xd_parts(), 17, 10, "bf16", dev, a,
+                                           batch_chunks=128, lanes=2)
+            line["shang_msad_eval"] = dataset_eval("BASELINE config 5 (real gt and label order, synthetic features)", config5_parts(),
+                                                   19, 5, "bf16", dev, a, batch_chunks=128, lanes=2)
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)

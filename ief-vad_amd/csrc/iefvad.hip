@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "attention_f32.h"
@@ -1485,6 +1486,50 @@ extern "C" int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t c
     if (ge != ncclSuccess) return fail("iefvad_gather_scores: ncclGroupEnd: %s", api->GetErrorString(ge));
     if (plan.my_count && gathered + plan.my_offset != local)
         HIP_TRY(hipMemcpyAsync(gathered + plan.my_offset, local, plan.my_count * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the whole-video path: gather the videos' rows into one (pinned) staging buffer
+// ------------------------------------------------------------------------------------------------
+extern "C" int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
+    if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather: null argument");
+    if (count == 0) return 0;
+    std::vector<size_t> off((size_t)count + 1);
+    off[0] = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        if (nbytes[i] && !srcs[i]) return fail("iefvad_host_gather: srcs[%lld] is null", (long long)i);
+        off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
+    }
+    const size_t total = off[(size_t)count];
+    int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (total < ((size_t)4 << 20)) nt = 1;               // a few MB: one thread is done before a second one has started
+    auto run = [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i)
+            if (nbytes[i]) memcpy((char*)dst + off[(size_t)i], srcs[i], nbytes[i]);
+    };
+    if (nt == 1) {
+        run(0, count);
+        return 0;
+    }
+    // contiguous runs of pieces, ~equal bytes each
+    std::vector<int64_t> cut((size_t)nt + 1, count);
+    cut[0] = 0;
+    int k = 1;
+    for (int64_t i = 0; i < count && k < nt; ++i)
+        if (off[(size_t)i + 1] >= total / nt * k) cut[(size_t)k++] = i + 1;
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < nt; ++t)
+            if (cut[(size_t)t + 1] > cut[(size_t)t]) pool.emplace_back(run, cut[(size_t)t], cut[(size_t)t + 1]);
+    } catch (...) {                                       // thread creation refused: finish the rest here
+        for (auto& th : pool) th.join();
+        run(cut[1], count);
+        run(0, cut[1]);
+        return 0;
+    }
+    run(0, cut[1]);
+    for (auto& th : pool) th.join();
     return 0;
 }
 

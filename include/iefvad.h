@@ -177,6 +177,12 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
                           const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
                           size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
 
+/* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
+ * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a
+ * pinned staging buffer that one asynchronous copy then sends to the device as iefvad_forward_videos's img_rows / ev_rows.
+ * Pure host code: all pointers are HOST pointers. */
+int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads);
+
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
  * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);

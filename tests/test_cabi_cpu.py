@@ -128,3 +128,19 @@ def test_shim_refuses_cpu_tensors():
     x = torch.zeros(1, 256, 768)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(x, x, None, None, None)
+
+
+def test_host_gather_concatenates_rows_without_a_gpu(lib):
+    """`iefvad_host_gather` (the loader side of iefvad_forward_videos): pieces of uneven size, empty pieces, one or several
+    threads, small and large totals -- the destination is the plain concatenation."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for sizes, threads in (([5, 0, 7, 1], 4), ([3 << 20, 11, 0, 2 << 20, 5 << 20, 1 << 20, 123457], 4), ([1 << 22] * 5, 16), ([9], 0)):
+        parts = [rng.integers(0, 255, n, dtype=np.uint8) for n in sizes]
+        dst = np.full(sum(sizes) + 8, 0xEE, np.uint8)
+        ptrs = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+        nb = (C.c_size_t * len(parts))(*sizes)
+        assert lib.iefvad_host_gather(dst.ctypes.data, ptrs, nb, len(parts), threads) == 0, L.last_error()
+        assert np.array_equal(dst[:-8], np.concatenate(parts)) and (dst[-8:] == 0xEE).all()
+    assert lib.iefvad_host_gather(None, None, None, 0, 4) == 0
+    assert lib.iefvad_host_gather(None, None, None, 3, 4) != 0 and "null" in L.last_error()

@@ -66,7 +66,12 @@ def test_forward_videos_is_bit_identical_to_the_padded_forward(compute, micro_ba
     got = ragged(model, vids)
     for k in want:
         assert got[k].shape == want[k].shape == (sum(EDGE_LENGTHS),)
-        assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+        if compute == "bf16" and k != "logits":
+            # the fused heads + fusion kernel (full grids) and the stand-alone fusion kernel sum a row's 768 weights in
+            # different orders; which one runs depends on the row count, and the tail now has fewer rows
+            assert float((got[k] - want[k]).abs().max()) <= 1e-6, k
+        else:
+            assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
 
 
 def test_forward_videos_large_batch_bf16_kernels_and_bf16x6_tolerance():
@@ -77,8 +82,9 @@ def test_forward_videos_large_batch_bf16_kernels_and_bf16x6_tolerance():
     vids = videos(lengths, seed=8)
     model, sd = make_model("bf16", K=10, outputs="scores")
     want, got = dense_reference(model, vids), ragged(model, vids)
-    for k in want:
-        assert torch.equal(got[k], want[k]), k
+    assert torch.equal(got["logits"], want["logits"])
+    for k in ("w_i_mean", "w_e_mean"):
+        assert torch.equal(got[k], want[k]), k        # both sides run the fused heads + fusion kernel here
     del model
     model, _ = make_model("bf16x6", K=10, outputs="scores")
     want, got = dense_reference(model, vids), ragged(model, vids)
@@ -115,7 +121,9 @@ def test_forward_videos_nan_rule_matches_the_host_rule(dtype):
         assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0)), i
     for a, b in zip(wi_h, wi_d):
         assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
-    assert np.isfinite(dev[1]).all() and np.isfinite(dev[4]).all()            # replaced
+    assert np.isfinite(dev[4]).all()                                          # NaN -> 0
+    # video 1: +-inf -> the dtype's max / min; 65504 is harmless, 3.4e38 overflows inside the first projection (in the reference too)
+    assert np.isfinite(dev[1]).all() if dtype == np.float16 else np.isnan(dev[1][256:]).all()
     assert np.isnan(dev[3]).all()                                             # inf without NaN: left alone, poisons its chunk
     assert all(np.isfinite(dev[i]).all() for i in (0, 2, 5))
     # nan_to_num=False: rows are used as they are
