@@ -27,6 +27,7 @@
 #include "outproj_ln_bf16.h"
 #include "refine_chain_bf16.h"
 #include "ragged.h"
+#include "loss.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -1486,6 +1487,45 @@ extern "C" int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t c
     if (ge != ncclSuccess) return fail("iefvad_gather_scores: ncclGroupEnd: %s", api->GetErrorString(ge));
     if (plan.my_count && gathered + plan.my_offset != local)
         HIP_TRY(hipMemcpyAsync(gathered + plan.my_offset, local, plan.my_count * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// training-side loss head, forward only (csrc/loss.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T) {
+    if (B <= 0 || T <= 0) return 0;
+    return ((size_t)B * T * 4 + (size_t)B) * sizeof(float) + 256;
+}
+
+extern "C" int iefvad_loss_forward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
+                                   const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
+                                   int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float* out, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+    if (!logits || !lengths || !targets || !out || !workspace) return fail("iefvad_loss_forward: null argument");
+    const bool heads = image_mu || event_mu || image_logvar || event_logvar;      // all four or none (none: CLAS2 alone)
+    if (heads && !(image_mu && event_mu && image_logvar && event_logvar))
+        return fail("iefvad_loss_forward: image_mu, event_mu, image_logvar, event_logvar must be given together");
+    if (B <= 0) return fail("iefvad_loss_forward: B must be positive (got %d)", B);
+    if (T != IEF_T) return fail("iefvad_loss_forward: kernels are built for T = %d (got %d)", IEF_T, T);
+    if (noise_model != IEFVAD_NOISE_GAUSSIAN && noise_model != IEFVAD_NOISE_STUDENT_T)
+        return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");
+    if (noise_model == IEFVAD_NOISE_STUDENT_T && !(nu > 0.f)) return fail("iefvad_loss_forward: nu must be positive for StudentT");
+    if (workspace_bytes < iefvad_loss_workspace_bytes(B, T)) return fail("iefvad_loss_forward: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int rows = heads ? B * T : 0;
+    float* part = (float*)workspace;
+    float* inst = part + (size_t)B * T * 4;
+    hipLaunchKernelGGL(iefvad_mil_topk_kernel, dim3(B), dim3(256), 0, stream, logits, (const int*)lengths, inst, T);
+    LossRowArgs ra;
+    ra.mu_i = image_mu; ra.mu_e = event_mu; ra.lv_i = image_logvar; ra.lv_e = event_logvar; ra.part = part; ra.rows = rows;
+    ra.lv_shift = noise_model == IEFVAD_NOISE_STUDENT_T ? logf(nu / (nu + 1.0f)) : 0.f;       // ucf_train.py:94-95
+    if (heads) hipLaunchKernelGGL(iefvad_loss_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ra);
+    LossFinishArgs fa;
+    fa.inst = inst; fa.targets = targets; fa.part = part; fa.out = out; fa.B = B; fa.rows = rows; fa.lambda_reg = lambda_reg;
+    fa.lambda_kl = lambda_kl;
+    hipLaunchKernelGGL(iefvad_loss_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -1,0 +1,148 @@
+// Training-side loss head, forward only: the three terms the reference's trainers add up
+// (/root/reference/train/ucf_train.py:68-101, train/xd_train.py:60-75), as device reductions over tensors the forward
+// already produces (logits, image_mu, event_mu, image_logvar, event_logvar):
+//   * CLAS2 (/root/reference/train/loss.py:18-30): per video i, p_i = mean of the k = int(len_i / 16 + 1) largest
+//     sigmoid(logit[i, 0:len_i]); binary cross entropy of p against (1 - labels[:, 0]), mean over the batch
+//     (torch's BCE clamps the logarithms at -100);
+//   * the regulariser (ucf_train.py:75-82): mean over all B*T rows of 1 - cosine_similarity(normalize(mu_i), normalize(mu_e))
+//     plus the mean of | ||mu_i|| - ||mu_e|| |;
+//   * the KL terms (ucf_train.py:84-98): -0.5 mean(1 + l - mu^2 - exp(l)) per modality, with l = logvar for the Gaussian
+//     noise model and logvar + log(nu / (nu + 1)) for Student-t.
+// No atomics: per-video and per-row partial results land in a workspace and ONE workgroup combines them in a fixed order,
+// so the losses are bit-reproducible from run to run.  The backward pass is not built.
+#pragma once
+#include "common.h"
+
+#define LOSS_T IEF_T
+
+// one workgroup (256 threads = the T snippets) per video: top-k mean of the sigmoid scores over the valid prefix
+__global__ __launch_bounds__(256) void iefvad_mil_topk_kernel(const float* logits, const int* lengths, float* inst, int T) {
+    __shared__ float s[LOSS_T];
+    const int v = blockIdx.x, t = threadIdx.x;
+    int len = lengths[v];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const int k = len / 16 + 1;                                  // int(lengths[i] / 16 + 1), loss.py:26
+    const float x = (t < len) ? 1.0f / (1.0f + expf(-logits[(size_t)v * T + t])) : -1.0f;     // sigmoid is in (0, 1): -1 never wins
+    s[t] = x;
+    __syncthreads();
+    // rank of this element among the valid ones (ties broken by index: any choice among equal values gives the same mean)
+    int rank = 0;
+    for (int u = 0; u < T; ++u) {
+        const float y = s[u];
+        rank += (y > x) || (y == x && u < t);
+    }
+    const int kk = k < len ? k : len;                            // topk raises for k > len (len = 0 never reaches the trainer)
+    float part = (t < len && rank < kk) ? x : 0.f;
+    part = wave_sum(part);
+    __shared__ float w[4];
+    if ((t & 63) == 0) w[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) inst[v] = kk > 0 ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)kk : 0.f;
+}
+
+// one wavefront per row: cosine / norm regulariser terms and the two KL sums of the row -> part[row][4]
+struct LossRowArgs {
+    const float* mu_i; const float* mu_e; const float* lv_i; const float* lv_e;     // [rows, 768]
+    float* part;                 // [rows][4]: 1 - cos, |norm_i - norm_e|, KL sum image, KL sum event
+    int rows;
+    float lv_shift;              // 0 (Gaussian) or log(nu / (nu + 1)) (StudentT)
+};
+__global__ __launch_bounds__(256) void iefvad_loss_rows_kernel(LossRowArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const size_t base = (size_t)row * IEF_D + 4 * lane;
+    f32x4 mi[3], me[3];
+    float sii = 0.f, see = 0.f, kli = 0.f, kle = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        mi[j] = *(const f32x4*)(a.mu_i + base + 256 * j);
+        me[j] = *(const f32x4*)(a.mu_e + base + 256 * j);
+        const f32x4 li = *(const f32x4*)(a.lv_i + base + 256 * j), le = *(const f32x4*)(a.lv_e + base + 256 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sii += mi[j][e] * mi[j][e];
+            see += me[j][e] * me[j][e];
+            const float l1 = li[e] + a.lv_shift, l2 = le[e] + a.lv_shift;
+            kli += 1.0f + l1 - mi[j][e] * mi[j][e] - expf(l1);
+            kle += 1.0f + l2 - me[j][e] * me[j][e] - expf(l2);
+        }
+    }
+    const float ni = sqrtf(wave_sum(sii)), ne = sqrtf(wave_sum(see));
+    kli = wave_sum(kli);
+    kle = wave_sum(kle);
+    // F.normalize (x / max(||x||, 1e-12)), then F.cosine_similarity of the normalised rows (each again divided by
+    // max(its norm, 1e-8)): ucf_train.py:75-77
+    const float ri = 1.0f / fmaxf(ni, 1e-12f), re = 1.0f / fmaxf(ne, 1e-12f);
+    float s2i = 0.f, s2e = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mi[j][e] *= ri;
+            me[j][e] *= re;
+            s2i += mi[j][e] * mi[j][e];
+            s2e += me[j][e] * me[j][e];
+        }
+    const float qi = 1.0f / fmaxf(sqrtf(wave_sum(s2i)), 1e-8f), qe = 1.0f / fmaxf(sqrtf(wave_sum(s2e)), 1e-8f);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dot += (mi[j][e] * qi) * (me[j][e] * qe);
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        float* p = a.part + (size_t)row * 4;
+        p[0] = 1.0f - dot;
+        p[1] = fabsf(ni - ne);
+        p[2] = kli;
+        p[3] = kle;
+    }
+}
+
+// ONE workgroup: fixed-order sums of the partials -> out[8] = classification, reg, cos, norm, kl, kl_image, kl_event, total
+struct LossFinishArgs {
+    const float* inst;           // [B] instance scores
+    const float* targets;        // [B] 1 = abnormal (1 - labels[:, 0]), loss.py:20
+    const float* part;           // [rows][4]
+    float* out;                  // [8]
+    int B, rows;
+    float lambda_reg, lambda_kl;
+};
+__global__ __launch_bounds__(256) void iefvad_loss_finish_kernel(LossFinishArgs a) {
+    __shared__ double red[5][256];
+    const int t = threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int v = t; v < a.B; v += 256) {
+        const float p = a.inst[v], y = a.targets[v];
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);      // F.binary_cross_entropy's clamp
+        acc[0] += (double)(-(y * lp + (1.0f - y) * lq));
+    }
+    for (int r = t; r < a.rows; r += 256)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1 + j] += (double)a.part[(size_t)r * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) red[j][t] = acc[j];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) red[j][t] += red[j][t + s];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double cls = red[0][0] / a.B;
+        const double nr = a.rows > 0 ? (double)a.rows : 1.0;       // rows == 0: the classification term alone was asked for
+        const double lcos = red[1][0] / nr, lnorm = red[2][0] / nr;
+        const double n = nr * IEF_D;
+        const double kli = -0.5 * red[3][0] / n, kle = -0.5 * red[4][0] / n;
+        a.out[0] = (float)cls;
+        a.out[1] = (float)(lcos + lnorm);
+        a.out[2] = (float)lcos;
+        a.out[3] = (float)lnorm;
+        a.out[4] = (float)(kli + kle);
+        a.out[5] = (float)kli;
+        a.out[6] = (float)kle;
+        a.out[7] = (float)(cls + a.lambda_reg * (lcos + lnorm) + a.lambda_kl * (kli + kle));
+    }
+}

@@ -273,7 +273,7 @@ class _RowStager:
     threads when the batch is large -- and sent with one asynchronous copy per modality on the current stream.  Nothing on
     the host reads the rows: the NaN scan of test.py:90-95 happens on the device (csrc/ragged.h)."""
 
-    def __init__(self, device, slots: int = 3):
+    def __init__(self, device, slots: int = 2):
         self.device = torch.device(device)
         self.bufs = [[None, None] for _ in range(slots)]
         self.events = [None] * slots
@@ -282,8 +282,17 @@ class _RowStager:
     def _buffer(self, slot, m, nbytes):
         b = self.bufs[slot][m]
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, pin_memory=True)
-            self.bufs[slot][m] = b
+            # pinning memory costs milliseconds per 100 MB: grow EVERY slot now (the first pass over a list is the warm-up,
+            # later passes must not meet a slot that was never used at this size), with head room for uneven batches
+            size = max(int(nbytes * 1.5), 1 << 22)
+            for s_ in range(len(self.bufs)):
+                for m_ in range(2):
+                    old = self.bufs[s_][m_]
+                    if old is None or old.numel() < size:
+                        if self.events[s_] is not None:
+                            self.events[s_].synchronize()
+                        self.bufs[s_][m_] = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+            b = self.bufs[slot][m]
         return b
 
     def upload(self, imgs, evs, dt):

@@ -26,7 +26,8 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_last_error",
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
-           "iefvad_videos_workspace_bytes", "iefvad_host_gather"]
+           "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward",
+           "iefvad_loss_workspace_bytes"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -107,6 +108,11 @@ def load_library() -> C.CDLL:
     lib.iefvad_forward_videos.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                           C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.iefvad_forward_videos.restype = C.c_int
+    lib.iefvad_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.iefvad_loss_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_loss_forward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.iefvad_loss_forward.restype = C.c_int
     lib.iefvad_host_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]
     lib.iefvad_host_gather.restype = C.c_int
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

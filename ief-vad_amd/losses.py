@@ -1,0 +1,71 @@
+"""Training-side loss head, FORWARD ONLY: device counterparts of the reference's loss terms with the
+reference's call shapes, computed by libiefvad (`iefvad_loss_forward`, csrc/loss.h) -- no torch op computes anything here.
+
+  * `CLAS2(logits, labels, lengths, device)`   -- /root/reference/train/loss.py:18-30
+  * `training_losses(outputs, labels, lengths, ...)` -- the sum the trainers form, /root/reference/train/ucf_train.py:68-101
+    (lambda_reg = lambda_kl = 1) and train/xd_train.py:60-75 (0.01, 0.01): classification + lambda_reg * (cosine + norm
+    regulariser of image_mu / event_mu) + lambda_kl * (Gaussian or Student-t KL of both modalities).
+
+The values are exact forward results on tensors `iefvad_amd.MMFMIL` returns in eval mode; no graph is recorded: the backward
+pass, the optimiser and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this build.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import torch
+
+from . import lib as _lib
+
+TERMS = ("classification", "reg", "cos", "norm", "kl", "kl_image", "kl_event", "total")
+
+
+def _run(logits, heads, labels, lengths, noise_model, nu, lambda_reg, lambda_kl) -> torch.Tensor:
+    if not logits.is_cuda:
+        raise RuntimeError("iefvad_amd.losses runs on a HIP device only; there is no CPU fallback")
+    dev = logits.device
+    B = int(logits.shape[0])
+    lg = logits.reshape(B, -1).float().contiguous()
+    T = int(lg.shape[1])
+    targets = (1 - labels[:, 0].reshape(B)).to(device=dev, dtype=torch.float32).contiguous()          # loss.py:20
+    lens = torch.as_tensor(lengths).reshape(B).to(device=dev, dtype=torch.int32).contiguous()
+    ptrs = [None] * 4
+    keep = []
+    if heads is not None:
+        for i, t in enumerate(heads):
+            t = t.reshape(B * T, -1).float().contiguous()
+            if t.shape[1] != 768 or t.device != dev:
+                raise ValueError("image_mu / event_mu / image_logvar / event_logvar must be [B, T, 768] tensors on the logits' device")
+            keep.append(t)
+            ptrs[i] = C.c_void_p(t.data_ptr())
+    if noise_model not in ("Gaussian", "StudentT"):
+        raise ValueError("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.")
+    lib = _lib.load_library()
+    need = lib.iefvad_loss_workspace_bytes(B, T)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.iefvad_loss_forward(C.c_void_p(lg.data_ptr()), ptrs[0], ptrs[1], ptrs[2], ptrs[3], C.c_void_p(lens.data_ptr()),
+                                     C.c_void_p(targets.data_ptr()), B, T,
+                                     _lib.NOISE_STUDENT_T if noise_model == "StudentT" else _lib.NOISE_GAUSSIAN, float(nu),
+                                     float(lambda_reg), float(lambda_kl), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                     ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("iefvad_loss_forward: " + _lib.last_error())
+    return out
+
+
+def CLAS2(logits: torch.Tensor, labels: torch.Tensor, lengths, device=None) -> torch.Tensor:
+    """Top-k MIL binary cross entropy, same arguments as the reference's CLAS2 (loss.py:18): `logits` [B, T, 1] (or [B, T]),
+    `labels` [B, C] one-hot with column 0 = normal, `lengths` [B].  Returns a 0-dim device tensor."""
+    return _run(logits, None, labels, lengths, "Gaussian", 1.0, 0.0, 0.0)[0]
+
+
+def training_losses(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, lengths, noise_model: str = "StudentT", nu: float = 8,
+                    lambda_reg: float = 1.0, lambda_kl: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Every term of the trainers' loss from the model's output dict (`logits`, `image_mu`, `event_mu`, `image_logvar`,
+    `event_logvar`): a dict of 0-dim device tensors keyed by `TERMS`."""
+    heads = (outputs["image_mu"], outputs["event_mu"], outputs["image_logvar"], outputs["event_logvar"])
+    out = _run(outputs["logits"], heads, labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
+    return {k: out[i] for i, k in enumerate(TERMS)}

@@ -138,3 +138,25 @@ def config5_lists(golden_dir: str):
         labels = [str(x) for x in g[f"{d}_labels"]]
         out[d] = (exact_lengths(seed, len(labels), frames // 16), labels, gt)
     return out
+
+
+LOSS_LENGTHS = [256, 37, 100, 16, 255, 1, 200, 64]
+
+
+def make_loss_inputs(seed: int, B: int = 8, T: int = 256, D: int = 768):
+    """Seeded stand-ins for a training batch's model outputs (f-4 loss head fixtures): logits [B,T,1], image_mu / event_mu /
+    image_logvar / event_logvar [B,T,D], one-hot labels [B,14] (column 0 = normal) and lengths.  One image_mu row is all
+    zero (the eps branches of F.normalize / F.cosine_similarity), a few logits tie exactly (top-k among equal scores)."""
+    rng = np.random.default_rng([seed, 31])
+    logits = (rng.standard_normal((B, T, 1)) * 2.0).astype(np.float32)
+    logits[0, 10:14, 0] = logits[0, 9, 0]                       # ties
+    logits[2, :, 0] = np.round(logits[2, :, 0] * 2) / 2         # many ties
+    out = {"logits": logits}
+    for k, sc, sh in (("image_mu", 0.5, 0.0), ("event_mu", 0.4, 0.05), ("image_logvar", 0.3, -0.5), ("event_logvar", 0.4, -0.2)):
+        out[k] = (rng.standard_normal((B, T, D)) * sc + sh).astype(np.float32)
+    out["image_mu"][1, 5] = 0.0
+    labels = np.zeros((B, 14), np.float32)
+    cls = [0, 3, 0, 7, 13, 0, 1, 2][:B]
+    labels[np.arange(B), cls] = 1.0
+    lengths = np.array(LOSS_LENGTHS[:B], np.int64)
+    return out, labels, lengths

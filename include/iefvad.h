@@ -177,6 +177,25 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
                           const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
                           size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
 
+/* ---- training-side loss head, FORWARD ONLY ---------------------------------------------------------
+ * The three terms the reference's trainers add up (/root/reference/train/ucf_train.py:68-101, train/xd_train.py:60-75), as
+ * device reductions over tensors iefvad_forward already produces:
+ *   out[0] classification  CLAS2(logits, labels, lengths) (/root/reference/train/loss.py:18-30): per video the mean of the
+ *                          int(len / 16 + 1) largest sigmoid(logit[0:len]), binary cross entropy against targets
+ *   out[1] reg = out[2] + out[3]: mean(1 - cosine_similarity(normalize(mu_i), normalize(mu_e))) + mean(| ||mu_i|| - ||mu_e|| |)
+ *   out[4] kl = out[5] + out[6]: -0.5 mean(1 + l - mu^2 - exp(l)) per modality, l = logvar (Gaussian) or
+ *                          logvar + log(nu / (nu + 1)) (StudentT; the trainers read model.temporal.nu, ucf_train.py:94-95)
+ *   out[7] total = classification + lambda_reg * reg + lambda_kl * kl   (1, 1 in ucf_train.py:100-102; 0.01, 0.01 in xd_train.py:73-75)
+ * logits [B, T]; the four 768-d tensors [B*T, 768]; lengths int32 [B] and targets fp32 [B] (1 = abnormal, i.e.
+ * 1 - labels[:, 0], loss.py:20) on the DEVICE; out: 8 fp32 on the device.  T must be 256.  Deterministic (no atomics).
+ * The four 768-d pointers may all be NULL: then only out[0] (and out[7] = out[0]) is computed -- CLAS2 alone.
+ * The backward pass and the optimiser step are not part of this library. */
+size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T);
+int iefvad_loss_forward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
+                        const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
+                        int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
  * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a
  * pinned staging buffer that one asynchronous copy then sends to the device as iefvad_forward_videos's img_rows / ev_rows.

@@ -173,3 +173,44 @@ def score_videos(model, videos: Sequence[Tuple[np.ndarray, np.ndarray]], maxlen:
         lg = o["logits"].reshape(-1, 1)
         out.append(torch.sigmoid(lg[0:n].squeeze(-1)).to(torch.float32).cpu().numpy())
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# training-side loss terms, forward only -- checker for csrc/loss.h
+# ----------------------------------------------------------------------------------------
+def loss_terms(logits, image_mu, event_mu, image_logvar, event_logvar, labels, lengths, noise_model="StudentT", nu=8,
+               lambda_reg=1.0, lambda_kl=1.0, dtype=torch.float64) -> Dict[str, float]:
+    """The sum the reference's trainers form (/root/reference/train/ucf_train.py:68-101, xd_train.py:60-75), restated with
+    explicit algebra: CLAS2 (/root/reference/train/loss.py:18-30: per video the mean of the int(len/16 + 1) largest
+    sigmoid(logit[0:len]); BCE against 1 - labels[:, 0] with torch's log clamp at -100), the cosine + norm regulariser of the
+    two mu tensors (ucf_train.py:75-82; F.normalize eps 1e-12, F.cosine_similarity eps 1e-8) and the Gaussian / Student-t KL
+    terms (:84-98).  Pinned by tests/golden/loss_terms.npz (reference CLAS2 + the trainers' torch calls)."""
+    lg = torch.as_tensor(logits).to(dtype)
+    B = lg.shape[0]
+    p = torch.sigmoid(lg.reshape(B, -1))
+    y = 1.0 - torch.as_tensor(labels).to(dtype)[:, 0]
+    inst = []
+    for i in range(B):
+        n = int(lengths[i])
+        k = int(n / 16 + 1)
+        v = torch.sort(p[i, :n], descending=True).values[:k]
+        inst.append(v.sum() / k)
+    inst = torch.stack(inst)
+    bce = -(y * torch.clamp(torch.log(inst), min=-100.0) + (1 - y) * torch.clamp(torch.log(1 - inst), min=-100.0))
+    cls = float(bce.mean())
+    mi, me = torch.as_tensor(image_mu).to(dtype), torch.as_tensor(event_mu).to(dtype)
+    ni, ne = torch.sqrt((mi * mi).sum(-1)), torch.sqrt((me * me).sum(-1))
+    ui = mi / torch.clamp(ni, min=1e-12).unsqueeze(-1)
+    ue = me / torch.clamp(ne, min=1e-12).unsqueeze(-1)
+    qi = torch.clamp(torch.sqrt((ui * ui).sum(-1)), min=1e-8)
+    qe = torch.clamp(torch.sqrt((ue * ue).sum(-1)), min=1e-8)
+    cos = ((ui / qi.unsqueeze(-1)) * (ue / qe.unsqueeze(-1))).sum(-1)
+    lcos, lnorm = float((1 - cos).mean()), float(torch.abs(ni - ne).mean())
+    sh = math.log(nu / (nu + 1)) if noise_model == "StudentT" else 0.0
+    kl = []
+    for mu, lv in ((mi, torch.as_tensor(image_logvar).to(dtype)), (me, torch.as_tensor(event_logvar).to(dtype))):
+        e = lv + sh
+        kl.append(float(-0.5 * (1 + e - mu * mu - torch.exp(e)).mean()))
+    reg, klsum = lcos + lnorm, kl[0] + kl[1]
+    return {"classification": cls, "reg": reg, "cos": lcos, "norm": lnorm, "kl": klsum, "kl_image": kl[0], "kl_event": kl[1],
+            "total": cls + lambda_reg * reg + lambda_kl * klsum}

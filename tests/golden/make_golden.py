@@ -250,7 +250,43 @@ def gen_config5_gt():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: (v.shape if v.ndim else int(v)) for k, v in out.items()})
 
 
+def gen_loss_case():
+    """f-4: the trainers' loss terms on seeded stand-ins of a batch's model outputs.  CLAS2 is the reference's own
+    function (/root/reference/train/loss.py:18-30 imports only torch); the trainer modules cannot be imported (wandb), so the
+    regulariser and KL terms are evaluated here with the torch calls train/ucf_train.py:75-98 makes, in its order.  Outputs only."""
+    import math
+    import torch.nn.functional as F
+    sys.path.insert(0, REF)
+    from train.loss import CLAS2
+    store = {}
+    for seed in (1, 2):
+        o, labels, lengths = synth.make_loss_inputs(seed)
+        t = {k: torch.from_numpy(v) for k, v in o.items()}
+        cls = CLAS2(t["logits"], torch.from_numpy(labels), torch.from_numpy(lengths), "cpu")
+        image_mu, event_mu = t["image_mu"], t["event_mu"]
+        cos_sim = F.cosine_similarity(F.normalize(image_mu, p=2, dim=-1), F.normalize(event_mu, p=2, dim=-1), dim=-1)   # :75-77
+        loss_cos = (1 - cos_sim).mean()                                                                                 # :78,82
+        loss_norm = torch.abs(torch.norm(image_mu, p=2, dim=-1) - torch.norm(event_mu, p=2, dim=-1)).mean()            # :79-82
+        vals = [float(cls), float(loss_cos), float(loss_norm)]
+        for noise, nu in (("Gaussian", 8), ("StudentT", 8), ("StudentT", 5)):
+            sh = math.log(nu / (nu + 1)) if noise == "StudentT" else 0.0                                                # :94-95
+            kl = []
+            for mu, lv in ((image_mu, t["image_logvar"]), (event_mu, t["event_logvar"])):
+                e = lv + sh
+                kl.append(float(-0.5 * torch.mean(1 + e - mu.pow(2) - e.exp())))                                        # :88-89,96-97
+            vals += kl
+        store[f"seed{seed}"] = np.array(vals, np.float64)
+    store["layout"] = np.array("classification, cos, norm, kl_image Gaussian, kl_event Gaussian, kl_image StudentT nu=8, kl_event, "
+                               "kl_image StudentT nu=5, kl_event")
+    path = os.path.join(HERE, "loss_terms.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, store["seed1"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":
+        gen_loss_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "config5":
         gen_config5_gt()
         sys.exit(0)
@@ -270,3 +306,4 @@ if __name__ == "__main__":
     gen_init_checksums()
     gen_sweep_case()
     gen_config5_gt()
+    gen_loss_case()

@@ -86,3 +86,20 @@ def test_oracle_harness_scores_match_reference_test_loop(golden_dir):
         ref = g["scores"][offs[i]:offs[i + 1]]
         assert s.shape == ref.shape
         assert np.abs(s - ref).max() < 2e-6
+
+
+def test_oracle_loss_terms_match_the_reference_fixture(golden_dir):
+    """f-4: the oracle's restatement of CLAS2 / regulariser / KL against tests/golden/loss_terms.npz, which make_golden.py
+    produced with the reference's own CLAS2 (train/loss.py:18-30) and the torch calls of train/ucf_train.py:75-98."""
+    import os
+    from iefvad_amd import synth
+    g = np.load(os.path.join(golden_dir, "loss_terms.npz"))
+    for seed in (1, 2):
+        o, labels, lengths = synth.make_loss_inputs(seed)
+        want = g[f"seed{seed}"]
+        for j, (noise, nu) in enumerate((("Gaussian", 8), ("StudentT", 8), ("StudentT", 5))):
+            t = orc.loss_terms(o["logits"], o["image_mu"], o["event_mu"], o["image_logvar"], o["event_logvar"], labels, lengths,
+                               noise_model=noise, nu=nu)
+            got = [t["classification"], t["cos"], t["norm"], t["kl_image"], t["kl_event"]]
+            ref = [want[0], want[1], want[2], want[3 + 2 * j], want[4 + 2 * j]]
+            assert np.allclose(got, ref, rtol=0, atol=2e-6), (seed, noise, nu, got, ref)
