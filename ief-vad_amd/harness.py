@@ -231,8 +231,9 @@ class _PinnedStager:
     memcpy, which also does the torch.cat of a packed batch) and sent with an asynchronous copy on the current stream;
     a buffer is reused only after the event behind its last copy has completed."""
 
-    def __init__(self, device, slots: int = 2):
+    def __init__(self, device, slots: int = 2, threads: int = 0):
         self.device = torch.device(device)
+        self.threads = threads or max(1, min(8, host_cpu_share() // 2))      # host threads of one staging copy
         self.bufs = [[None, None] for _ in range(slots)]      # per slot: image / event pinned byte buffers
         self.events = [None] * slots
         self.turn = 0
@@ -273,8 +274,9 @@ class _RowStager:
     threads when the batch is large -- and sent with one asynchronous copy per modality on the current stream.  Nothing on
     the host reads the rows: the NaN scan of test.py:90-95 happens on the device (csrc/ragged.h)."""
 
-    def __init__(self, device, slots: int = 2):
+    def __init__(self, device, slots: int = 2, threads: int = 0):
         self.device = torch.device(device)
+        self.threads = threads or max(1, min(8, host_cpu_share() // 2))      # host threads of one staging copy
         self.bufs = [[None, None] for _ in range(slots)]
         self.events = [None] * slots
         self.turn = 0
@@ -316,7 +318,7 @@ class _RowStager:
             sizes = (C.c_size_t * n)(*[l * D * esize for l in lens])
             for host, parts in zip(hosts, (imgs, evs)):
                 ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
-                if lib.iefvad_host_gather(C.c_void_p(host.data_ptr()), ptrs, sizes, n, 4) != 0:
+                if lib.iefvad_host_gather(C.c_void_p(host.data_ptr()), ptrs, sizes, n, self.threads) != 0:
                     raise RuntimeError("iefvad_host_gather: " + _lib.last_error())
         else:                                                     # a widened (mixed-dtype) batch: torch casts while copying
             off = 0

@@ -1,9 +1,13 @@
 #!/bin/bash
-# Round-2 measurement set, run on the GPU box from the repo root:  bash tools/collect_profiles.sh
-# Writes everything under gpurun_out/r02/; the summaries worth keeping are copied to profiles/ by hand afterwards.
+# Measurement set of a round, run on the GPU box from the repo root:  bash tools/collect_profiles.sh [r03] [head]
+# Writes everything under gpurun_out/<round>/; the summaries worth keeping are copied to profiles/<round>_* afterwards
+# (tools/keep_profiles.sh).  `head` = the commit the box's snapshot was taken from (there is no .git on the box).
 set -u
+RND="${1:-r03}"
+HEAD="${2:-unknown}"
+export IEFVAD_HEAD="$HEAD"
 R="$PWD"
-O="$R/gpurun_out/r02"
+O="$R/gpurun_out/$RND"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py"
@@ -29,18 +33,31 @@ for mode in bf16 bf16x6; do
       -d "$O/pmc_write_$mode" -o p -- python3 "$B" --steps 1 --warmup 1 --chunks 1024 --compute $mode $QUIET > /dev/null 2> "$O/pmc_write_$mode.log"
   python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_$mode" "$O/pmc_fetch_$mode" "$O/pmc_write_$mode" > "$O/pmc_summary_$mode.txt" 2>&1
 done
-K="iefvad_gemm_bf16_pipe_kernel|iefvad_gemm_bf16_w256_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_bf16_kernel"
+SRC="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024"
+K="iefvad_gemm_bf16_w256_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_bf16_kernel"
+# algorithmic bytes of the six projection launches of a 262,144-row pass (bf16 mode, outputs=scores), KB per row, both modalities:
+# in_proj x2: read 3 (bf16 A), write 9 (bf16 q|k|v); out_proj+LN x2: read 3 + 6 (fp32 residual), write 6 fp32 + 3 bf16 (layer 0) / 3 bf16
+# (layer 1); heads+fusion: read 3, write 3 (fp32 z) + 0.1; refinement chain: read 3 (z), write 0.004
 python3 "$R/tools/hbm_traffic.py" "$(find "$O/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)" "$(find "$O/pmc_write_bf16" -name '*counter_collection.csv' | head -1)" \
-    "$K" 262144 "$O/gemm_bf16_hbm_traffic.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024 --compute bf16 (one micro-batch of 1024 chunks = 262144 rows per launch), MI355X, round 2" > /dev/null 2>&1
+    "$K" 262144 "$O/gemm_bf16_hbm_traffic.json" "$SRC --compute bf16 (one micro-batch of 1024 chunks = 262144 rows per launch), MI355X, $RND, head $HEAD" \
+    $(python3 -c "print(262144*1024*(3+3+3+6+3+6+3+3)/6, 262144*1024*(9+9+9+3+3.1+0.004)/6)") \
+    "mean over the 6 projection launches of one pass: 2 x in_proj (3 KB/row read, 9 written), 2 x out_proj+LayerNorm (9 read; 9 / 3 written), heads+fusion (3 / 3.1), refinement chain of 2K projections + scorer (3 / 0.004); weights <= 24 MB per launch" > /dev/null 2>&1
 K=iefvad_gemm_split_n128_kernel
 python3 "$R/tools/hbm_traffic.py" "$(find "$O/pmc_fetch_bf16x6" -name '*counter_collection.csv' | head -1)" "$(find "$O/pmc_write_bf16x6" -name '*counter_collection.csv' | head -1)" \
-    $K 262144 "$O/gemm_split_hbm_traffic.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024 --compute bf16x6 (262144 rows per launch), MI355X, round 2" > /dev/null 2>&1
+    $K 262144 "$O/gemm_split_hbm_traffic.json" "$SRC --compute bf16x6 (262144 rows per launch), MI355X, $RND, head $HEAD" \
+    1432400000 1288400000 "mean over the 25 GEMM launches of one 262144-row pass: A (fp32) + residual reads and C writes; W is 3 bf16 planes (<= 10.6 MB per launch)" > /dev/null 2>&1
 
-echo "[4] per-video pattern"
+echo "[4] split GEMM: random vs all-zero operands (the power-envelope probe), with the in-kernel clock"
+for z in 0 1; do
+  if [ $z = 1 ]; then export GS_ZERO=1; else unset GS_ZERO; fi
+  "$R/tools/gemm_tune_split" > "$O/gemm_split_tune_zero$z.log" 2>&1
+  "$R/tools/gemm_tune_split_clk" > "$O/gemm_split_clk_zero$z.log" 2>&1
+done
+unset GS_ZERO
+
+echo "[5] per-video pattern"
 python3 "$R/tools/latency_probe.py" > "$O/latency.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_b1" -o t -- python3 "$R/tools/b1_loop.py" > /dev/null 2> "$O/trace_b1.log"
-python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_b1" -name '*kernel_stats.csv' | head -1)" "$O/b1_kernel_stats.csv" > /dev/null
-echo "[5] BASELINE config 5 (K=5, Shang+MSAD-sized, bf16): kernel stats + PMC counters"
+echo "[6] BASELINE config 5 (K=5, Shang+MSAD lists, bf16): kernel stats + PMC counters"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_cfg5" -o t -- python3 "$R/tools/config5_profile.py" 5 > "$O/config5_run.log" 2> "$O/trace_cfg5.log"
 python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_cfg5" -name '*kernel_stats.csv' | head -1)" "$O/config5_kernel_stats.csv" > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv \
@@ -48,6 +65,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_cfg5" -o p -- python3 "$R/tools/config5_profile.py" 2 > /dev/null 2> "$O/pmc_fetch_cfg5.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_cfg5" -o p -- python3 "$R/tools/config5_profile.py" 2 > /dev/null 2> "$O/pmc_write_cfg5.log"
 python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_cfg5" "$O/pmc_fetch_cfg5" "$O/pmc_write_cfg5" > "$O/pmc_summary_config5.txt" 2>&1
+echo "[7] packed evaluation loop: where the wall clock goes"
+python3 "$R/tools/ragged_profile.py" > "$O/ragged_profile.log" 2>&1
 # keep the merge-back small: the raw traces are large
 find "$O" -name '*kernel_trace.csv' -size +8M -delete
 find "$O" -name '*.db' -delete

@@ -4,7 +4,10 @@ separately, as MI355X_MICROARCH.md's HBM section prescribes), calibrated on iefv
 known byte count in the same passes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled when the calibration
 shows 1/2).  The kernel argument may name several substrings joined by '|' (two tilings of one GEMM): the mean is over all
 their launches.   usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring>
-                                   <rows per launch> <out.json> "<source description>" """
+                                   <rows per launch> <out.json> "<source description>" [<algorithmic read bytes per launch>
+                                   <algorithmic write bytes per launch> "<how they are counted>"]
+The JSON names the kernels it covers and the git head it was collected at: bench.py refuses a figure whose kernel list does
+not match the kernels the build dispatches."""
 import csv
 import json
 import sys
@@ -42,5 +45,14 @@ res = {"source": source, "kernel": kname, "launches_measured": kf[1], "rows_per_
                       f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}",
        "read_bytes_per_launch": kf[0] * 1024 * fetch_scale, "write_bytes_per_launch": kw[0] * 1024,
        "traffic_bytes_per_launch": kf[0] * 1024 * fetch_scale + kw[0] * 1024}
+subs = kname.split("|")
+res["kernels"] = subs
+res["per_kernel_bytes_per_launch"] = {sub: {"read": pick(f, sub)[0] * 1024 * fetch_scale, "write": pick(w, sub)[0] * 1024, "launches": pick(f, sub)[1]}
+                                      for sub in subs if pick(f, sub) and pick(w, sub)}
+res["head"] = __import__("os").environ.get("IEFVAD_HEAD")      # the commit the box's snapshot was taken from (no .git on the box)
+if len(sys.argv) > 9:
+    ar, aw = float(sys.argv[7]), float(sys.argv[8])
+    res["algorithmic_bytes_per_launch"] = {"read": ar, "write": aw, "note": sys.argv[9]}
+    res["traffic_over_algorithmic"] = res["traffic_bytes_per_launch"] / (ar + aw)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

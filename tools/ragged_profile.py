@@ -36,7 +36,7 @@ def main():
         model.load_state_dict(synth.make_state_dict(17, 768, 2, K))
         model = model.to(dev).eval()
         n = int(lengths.sum())
-        for bcs in (bc, 2 * bc, 4 * bc, 8 * bc, 16 * bc):
+        for bcs in (bc, 2 * bc, 4 * bc):
           for lanes in (1, 2, 3):
             best = 1e9
             for rep in range(4):
