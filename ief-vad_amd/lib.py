@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiefvad.so")
+LIB_PATH = os.environ.get("IEFVAD_LIB") or os.path.join(_HERE, "libiefvad.so")      # IEFVAD_LIB: A/B builds of the same ABI (tools)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 3

@@ -37,6 +37,13 @@ if ln_f is None:        # bf16 mode with the fused out_proj + LayerNorm kernel: 
     cal_name = "iefvad_scorer_kernel"
     ln_f, ln_w = pick(f, cal_name), pick(w, cal_name)
     ln_bytes = rows * 768 * 4
+if ln_f is None:        # ... and with the refinement chain (scorer inside it): the input cast reads both fp32 blocks once
+    cal_name = "iefvad_cast_kernel"
+    def biggest(path, counter):      # the full-size launch (fp32 inputs of the micro-batch), not set_weights' small conversions
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and cal_name in r["Kernel_Name"]]
+        return (max(vals), 1)
+    ln_f, ln_w = biggest(fetch_csv, "FETCH_SIZE"), biggest(write_csv, "WRITE_SIZE")
+    ln_bytes = 2 * rows * 768 * 4
 fetch_scale = round(ln_bytes / (ln_f[0] * 1024))               # 2 on gfx950
 kf, kw = pick(f, kname), pick(w, kname)
 res = {"source": source, "kernel": kname, "launches_measured": kf[1], "rows_per_launch": rows,
