@@ -4,18 +4,14 @@
 // Unfused, every step is two projection launches that move 12 KB per snippet through HBM (bf16 z in, bf16 h out and
 // back in, fp32 z in and out, bf16 z out): 2K launches, HBM-bound.  Here a workgroup owns 64 rows for
 // the whole chain:
-//   * z stays FP32 IN REGISTERS (8 waves x [64 rows x 96 columns] = 96 VGPRs per lane), next to 48 accumulator registers
-//     (a wave computes its 96 columns in two passes of 48);
+//   * z stays FP32 IN REGISTERS (8 waves x [64 rows x 96 columns] = 96 VGPRs per lane), next to 96 accumulator registers;
 //   * ONE 96 KB bf16 activation image in LDS alternates between bf16(z) (operand of W1) and h (operand of W2): each is
 //     dead when the other is written (two workgroup barriers per projection, nothing else synchronises the waves);
-//   * the weights stream straight into registers: every wave reads ITS OWN 96 output columns of W1_0, W2_0, W1_1, ... as
-//     one linear sequence of 1 KB pieces (one piece = one MFMA fragment of the wave, laid out in lane order by
-//     iefvad_chain_pack_kernel at iefvad_set_weights; the biases ride the same stream as pieces in the accumulator's lane
-//     order), six pieces (24 registers) in flight per wave, each register set refilled right after the four MFMAs that
-//     read it -- no LDS ring, no barrier, hipcc's own counted s_waitcnt vmcnt, and the stream keeps running across
-//     projection boundaries.  (Round 3's first version filled a private LDS ring by LDS-DMA: an LDS-DMA instruction costs
-//     its wave 60-180 issue cycles per KB beside 64 cycles of MFMA work for that KB, and the kernel sat at 0.50 MFMA-busy and
-//     65 GB/s of weight stream per CU where the stream alone runs 110-120: tools/ingest_probe.hip, tools/refine_chain_bf16_v1_ldsdma_ring.h.)
+//   * the weights never touch registers on their way in: every wave streams ITS OWN 96 output columns of W1_0, W2_0,
+//     W1_1, ... as one linear sequence of 1 KB pieces (one piece = one MFMA fragment of the wave, laid out in lane
+//     order by iefvad_chain_pack_kernel at iefvad_set_weights; the projection's 96 bias values ride the same stream as
+//     one more piece) through a PRIVATE 8-piece LDS ring filled by LDS-DMA, ordered by the wave's own counted
+//     s_waitcnt vmcnt(7) -- no barrier, no shared ring, and the stream keeps running across projection boundaries;
 //   * the MFMA is issued with the operands swapped (A = weight fragment, B = activation fragment), so a lane holds four
 //     CONSECUTIVE output columns of one row: h / bf16(z) go back into the image as one 8-byte LDS store per tile, and the
 //     products and their k order are those of the projection kernels (gemm_bf16.h): z and the logits are bit-identical
@@ -23,7 +19,7 @@
 //   * the scorer runs on the resident state: the final z is parked in LDS (fp32, 32 rows at a time) and reduced by the
 //     scorer kernel's own code, 4 bytes per snippet leave the chip (plus z itself when the caller asked for `fused`).
 // HBM traffic of the tail per snippet: 3 KB in (z from the heads + fusion kernel), 4 B out, against 10 x 12 KB.
-// The weight stream is what feeds it: 2K x 1.2 MB per 64 rows from L2 (every workgroup reads the same bytes).
+// The weight stream is what bounds it: 2K x 1.18 MB per 64 rows from L2 (every workgroup reads the same bytes).
 #pragma once
 #include "gemm_bf16.h"
 #include "rowops.h"
@@ -31,29 +27,26 @@
 #define RC_BM 64
 #define RC_IMG_BYTES (RC_BM * IEF_D * 2)                    // 98,304 B: [64 rows][768 k] bf16, 16-byte chunks XOR-swizzled
 #define RC_NW 8                                             // waves per workgroup
+#define RC_SLOTS 8                                          // pieces of 1 KB in a wave's private ring
+#define RC_LDS_BYTES (RC_IMG_BYTES + RC_NW * RC_SLOTS * 1024)   // 163,840 B = all of a CU's LDS
 #define RC_KT (IEF_D / 32)                                  // 24 k-steps of 32
 #define RC_NB 6                                             // 16-column tiles per wave (96 columns)
 #define RC_WCOLS (16 * RC_NB)                               // columns per wave
 // A wave computes its 64 x 96 block in TWO passes over k, three column tiles (48 accumulator registers) each: with all six
-// tiles live beside the 96 registers of z hipcc spills ~140 registers per projection around the main loop.  The activation
-// image is read twice per projection instead.
+// tiles live beside the 96 registers of z hipcc spills ~140 registers per projection around the main loop, and the spill
+// reloads (ordinary loads) drain the LDS-DMA ring.  The activation image is read twice per projection instead.
 #define RC_NPASS 2
 #define RC_NBP (RC_NB / RC_NPASS)                           // column tiles per pass
-#define RC_PASS_PIECES (RC_KT * RC_NBP + RC_NBP)            // a pass's 72 weight fragments + its three bias pieces
+#define RC_PASS_PIECES (RC_KT * RC_NBP + 1)                 // a pass's 72 weight fragments + its 48 bias values
 #define RC_PIECES (RC_NPASS * RC_PASS_PIECES)               // pieces per projection and wave
-#define RC_DEPTH 6                                          // weight pieces in flight per wave (a ring of 6 x 4 registers)
-#define RC_PAD_PIECES RC_DEPTH                              // zero pieces behind a wave's stream (the ring reads ahead)
-#define RC_PARK_BYTES (4 * RC_NBP * 64 * 8)                 // per wave: the h tiles of a first projection's pass 0 wait here (6 KB)
-#define RC_LDS_BYTES (RC_IMG_BYTES + RC_NW * RC_PARK_BYTES) // 147,456 B
+#define RC_PAD_PIECES RC_SLOTS                              // zero pieces behind a wave's stream (the ring reads ahead)
 
 static inline size_t chain_wave_stride_bytes(int K) { return ((size_t)2 * K * RC_PIECES + RC_PAD_PIECES) * 1024; }
 static inline size_t chain_stream_bytes(int K) { return RC_NW * chain_wave_stride_bytes(K); }
 
-// ---- the weight stream.  Per wave w and projection g: pass 0's pieces, then pass 1's; a pass = its 72 weight pieces in
-// (k-step kt, column tile b) order, then its three bias pieces.  Weight piece, lane l = (r = l & 15, q = l >> 4):
+// ---- the weight stream.  Piece (wave w, projection g, k-step kt, column tile b), lane l = (r = l & 15, q = l >> 4):
 // 8 bf16 = W_g[96 w + 16 b + r][32 kt + 8 q .. + 7], i.e. the lane's A-operand fragment of v_mfma_f32_16x16x32_bf16;
-// bias piece b: lane (m, q) holds bias_g[96 w + 16 b + 4 q .. + 3], the four columns its accumulator registers of tile b
-// cover.  One thread per 16 bytes.
+// piece (w, g, bias): floats 0..95 = bias_g[96 w ..], the rest zero.  One thread per 16 bytes.
 struct ChainPackArgs {
     const bf16_t* W[2 * IEFVAD_MAX_STEPS];     // [768, 768] bf16 each: W1_0, W2_0, W1_1, ...
     const float* bias[2 * IEFVAD_MAX_STEPS];
@@ -77,10 +70,8 @@ __global__ __launch_bounds__(256) void iefvad_chain_pack_kernel(ChainPackArgs a)
                 const int kt = pi / RC_NBP, b = RC_NBP * pass + pi % RC_NBP;
                 const int r = lane & 15, q = lane >> 4;
                 val = *(const f32x4*)(a.W[g] + (size_t)(RC_WCOLS * w + 16 * b + r) * IEF_D + 32 * kt + 8 * q);
-            } else {
-                // bias piece b of the pass, in the accumulator's lane order: lane (m, q) needs columns 16 b + 4 q .. + 3
-                const int b = RC_NBP * pass + (pi - RC_KT * RC_NBP), q = lane >> 4;
-                val = *(const f32x4*)(a.bias[g] + RC_WCOLS * w + 16 * b + 4 * q);
+            } else if (lane < 4 * RC_NBP) {
+                val = *(const f32x4*)(a.bias[g] + RC_WCOLS * w + 16 * RC_NBP * pass + 4 * lane);
             }
         }
         *(f32x4*)(a.stream + u * 16) = val;
@@ -109,14 +100,17 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
     const int m = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * RC_BM;
 
-    // ---- the wave's weight stream: RC_DEPTH pieces in flight, in registers
+    // ---- the wave's weight stream and its private ring
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(args.stream + (size_t)wave * args.wave_stride), 0,
                                                       (int)args.wave_stride, 0x00020000);
+    const int ring = RC_IMG_BYTES + wave * (RC_SLOTS * 1024);
     const int vlane = lane * 16;
-#define RC_LOAD(piece_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vlane, (int)((piece_) << 10), 0))
-    f32x4 rg[RC_DEPTH];
+#define RC_DMA(piece_)                                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + ring + (((piece_) & (RC_SLOTS - 1)) << 10)), \
+                                             16, vlane, (int)((piece_) << 10), 0, 0)
+#define RC_WAIT_PIECE() asm volatile("s_waitcnt vmcnt(7)" ::: "memory")      /* RC_SLOTS - 1 */
 #pragma unroll
-    for (int s = 0; s < RC_DEPTH; ++s) rg[s] = RC_LOAD(s);
+    for (int s = 0; s < RC_SLOTS; ++s) RC_DMA(s);
 
     // ---- state: z[a][b] = rows 16 a + m, columns 96 wave + 16 b + 4 q .. + 3 (the swapped-operand accumulator map)
     f32x4 z[4][RC_NB];
@@ -132,7 +126,11 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
     // {0-3, 12-15, 20-27}, ... of MI355X_MICROARCH.md cover all sixteen 16-byte slots of a bank row) and 2-way -- the minimum
     // for sixteen rows at one 8-byte column -- for the ds_write_b64 tile stores (c ^ 2 r, the first version, was 4-way there:
     // 2.4e8 conflict cycles per launch, profiles/r03_kernel_pmc_summary_bf16.txt).
+#ifdef RC_SWZ2
+    const int sw = (2 * m) & 15;      // A/B: the first version's swizzle
+#else
     const int sw = m;
+#endif
     int rd[4];                                      // fragment read offsets for kt & 3 = 0..3 (add 24,576 a + 256 (kt >> 2))
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd[j] = m * (IEF_D * 2) + (((4 * j + q) ^ sw) & 15) * 16;
@@ -141,7 +139,6 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
         const int c = (RC_WCOLS / 8) * wave + 2 * b + (q >> 1);
         return (16 * a + m) * (IEF_D * 2) + ((c & ~15) | ((c ^ sw) & 15)) * 16 + (q & 1) * 8;
     };
-    char* park = lds + RC_IMG_BYTES + wave * RC_PARK_BYTES + lane * 8;      // tile (a, b) of pass 0: + (a * RC_NBP + b) * 512
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -151,17 +148,26 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
 
     const float lambda = args.lambda;
     const int G = 2 * args.K;
-    int p = 0;                                      // next piece of the stream to consume (pieces p .. p + 5 are in flight)
+    int p = 0;                                      // next piece of the stream to consume
     for (int g = 0; g < G; ++g) {
         const bool first = (g & 1) == 0;            // h = relu(z W1^T + b1); else z <- z - lambda (h W2^T + b2)
+        bf16x4_t hp[4][RC_NBP];                     // pass 0 of a first projection: its h tiles wait here for the image
 #pragma unroll
         for (int pass = 0; pass < RC_NPASS; ++pass) {
-            // ring position of the pass's piece i: (i + 3 pass) % 6 -- a pass is 75 pieces = 3 mod 6, a projection 150 = 0 mod 6
             f32x4 acc[4][RC_NBP];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < RC_NBP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            // Software-pipelined over the pass's 72 pieces: while the four MFMAs of piece p issue, the fragment of piece p + 1 is
+            // already on its way from the ring into the other register set, and the ring slot of piece p is being refilled.  (The
+            // first version read, waited, refilled and only then multiplied: a wave's own read latency + DMA issue + MFMA chain,
+            // ~260 cycles per piece, bounded the kernel at 0.50 MFMA-busy and 65 GB/s of weight stream per CU, while the stream
+            // alone runs at 110 GB/s: tools/ingest_probe.hip, profiles/r03_chain_ingest_probe.log.)
+            f32x4 gbuf[2];
+            RC_WAIT_PIECE();                                          // the pass's first piece has landed
+            gbuf[0] = *(const f32x4*)(lds + ring + ((p & (RC_SLOTS - 1)) << 10) + vlane);
 #pragma unroll 1
             for (int k4 = 0; k4 < RC_KT / 4; ++k4) {
 #pragma unroll
@@ -169,52 +175,52 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                     f32x4 ga[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) ga[a] = *(const f32x4*)(lds + rd[j] + a * (16 * IEF_D * 2) + k4 * 256);
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int b = 0; b < RC_NBP; ++b) {
-                        const int ri = (j * RC_NBP + b + RC_NBP * pass) % RC_DEPTH;      // 12 pieces per iteration = 0 mod 6
-                        const f32x4 w = rg[ri];
+                        constexpr int kPar = 0;
+                        const int cur = (j * RC_NBP + b + kPar) & 1;      // 12 pieces per iteration: the parity is the same in every iteration
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // piece p (and ga) are in registers: slot p may be refilled
+                        RC_DMA(p + RC_SLOTS);
+                        RC_WAIT_PIECE();                                      // pieces p + 1 .. p + 8 in flight -> p + 1 has landed
+                        gbuf[cur ^ 1] = *(const f32x4*)(lds + ring + (((p + 1) & (RC_SLOTS - 1)) << 10) + vlane);   // (after the pass's last piece: the bias piece, unused)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, ga[a]),
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gbuf[cur]), __builtin_bit_cast(bf16x8, ga[a]),
                                                                                 acc[a][b], 0, 0, 0);
-                        rg[ri] = RC_LOAD(p + RC_DEPTH);
-                        __builtin_amdgcn_sched_barrier(0);      // keep the refill HERE: hipcc otherwise sinks the loads and drains the ring
+                        __builtin_amdgcn_sched_barrier(0);
                         ++p;
                     }
                 }
             }
 
-            // ---- the pass's epilogue; its three bias pieces are the next three of the ring
-            f32x4 bias[RC_NBP];
-#pragma unroll
-            for (int b = 0; b < RC_NBP; ++b) {
-                const int ri = (RC_KT * RC_NBP + b + RC_NBP * pass) % RC_DEPTH;
-                bias[b] = rg[ri];
-                rg[ri] = RC_LOAD(p + RC_DEPTH);
-                ++p;
-            }
+            // ---- the pass's epilogue.  Its bias piece: 48 floats, lane (m, q) needs floats 16 b + 4 q .. + 3.
+            RC_WAIT_PIECE();
+            const char* bp = lds + ring + ((p & (RC_SLOTS - 1)) << 10) + 16 * q;
             if (pass == RC_NPASS - 1) GB2_BARRIER();      // every wave is done reading the image: it may be rewritten
             if (first) {
 #pragma unroll
-                for (int b = 0; b < RC_NBP; ++b)
+                for (int b = 0; b < RC_NBP; ++b) {
+                    const f32x4 bv = *(const f32x4*)(bp + 64 * b);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        f32x4 v = acc[a][b] + bias[b];
+                        f32x4 v = acc[a][b] + bv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
-                        if (pass == 0) *(bf16x4_t*)(park + (a * RC_NBP + b) * 512) = to_bf16x4(v);      // waits for the image in the wave's own park
+                        if (pass == 0) hp[a][b] = to_bf16x4(v);
                         else {
-                            *(bf16x4_t*)(lds + img_off(a, b)) = *(const bf16x4_t*)(park + (a * RC_NBP + b) * 512);
+                            *(bf16x4_t*)(lds + img_off(a, b)) = hp[a][b];
                             *(bf16x4_t*)(lds + img_off(a, RC_NBP + b)) = to_bf16x4(v);
                         }
                     }
+                }
             } else {
 #pragma unroll
-                for (int b = 0; b < RC_NBP; ++b)
+                for (int b = 0; b < RC_NBP; ++b) {
+                    const f32x4 bv = *(const f32x4*)(bp + 64 * b);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const f32x4 v = acc[a][b] + bias[b];
+                        const f32x4 v = acc[a][b] + bv;
                         const int bb = RC_NBP * pass + b;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) z[a][bb][e] = __builtin_fmaf(-lambda, v[e], z[a][bb][e]);
@@ -223,17 +229,17 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                             *(bf16x4_t*)(lds + img_off(a, bb)) = to_bf16x4(z[a][bb]);
                         }
                     }
+                }
             }
-            if (pass == RC_NPASS - 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                GB2_BARRIER();                            // the image holds the next operand
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RC_DMA(p + RC_SLOTS);                         // the bias piece's slot is free
+            ++p;
+            if (pass == RC_NPASS - 1) GB2_BARRIER();      // the image holds the next operand
         }
     }
-#undef RC_LOAD
-    // the ring's read-ahead (zero pad pieces) is still in flight: keep it alive until it has landed
-#pragma unroll
-    for (int s = 0; s < RC_DEPTH; ++s) asm volatile("" :: "v"(rg[s]));
+#undef RC_DMA
+#undef RC_WAIT_PIECE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's read-ahead (pad pieces) must land before the LDS is released
 
     // ---- final state out (only when the caller asked for `fused`)
     if (args.z_out) {
