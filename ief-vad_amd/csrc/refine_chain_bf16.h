@@ -37,13 +37,21 @@
 // A wave computes its 64 x 96 block in TWO passes over k, three column tiles (48 accumulator registers) each: with all six
 // tiles live beside the 96 registers of z hipcc spills ~140 registers per projection around the main loop.  The activation
 // image is read twice per projection instead.
-#define RC_NPASS 2
+#ifndef RC_NPASS
+#define RC_NPASS 2                                          // -DRC_NPASS=3 (32 accumulator registers, 10 pieces in flight): measured equal (profiles/r03_chain_kernel_ab.log)
+#endif
 #define RC_NBP (RC_NB / RC_NPASS)                           // column tiles per pass
-#define RC_PASS_PIECES (RC_KT * RC_NBP + RC_NBP)            // a pass's 72 weight fragments + its three bias pieces
+#define RC_PASS_PIECES (RC_KT * RC_NBP + RC_NBP)            // a pass's weight fragments + its bias pieces (75 / 50)
 #define RC_PIECES (RC_NPASS * RC_PASS_PIECES)               // pieces per projection and wave
-#define RC_DEPTH 6                                          // weight pieces in flight per wave (a ring of 6 x 4 registers)
+#if RC_NPASS == 2
+#define RC_DEPTH 6                                          // weight pieces in flight per wave (a ring of DEPTH x 4 registers)
+#define RC_KUNROLL 4                                        // k-steps per loop iteration: KUNROLL x NBP pieces = 0 mod DEPTH
+#else
+#define RC_DEPTH 10                                         // 50 pieces per pass = 0 mod 10; the k loop is fully unrolled
+#define RC_KUNROLL RC_KT
+#endif
 #define RC_PAD_PIECES RC_DEPTH                              // zero pieces behind a wave's stream (the ring reads ahead)
-#define RC_PARK_BYTES (4 * RC_NBP * 64 * 8)                 // per wave: the h tiles of a first projection's pass 0 wait here (6 KB)
+#define RC_PARK_BYTES ((RC_NPASS - 1) * 4 * RC_NBP * 64 * 8) // per wave: the h tiles of a first projection's earlier passes wait here
 #define RC_LDS_BYTES (RC_IMG_BYTES + RC_NW * RC_PARK_BYTES) // 147,456 B
 
 static inline size_t chain_wave_stride_bytes(int K) { return ((size_t)2 * K * RC_PIECES + RC_PAD_PIECES) * 1024; }
@@ -137,11 +145,14 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd[j] = m * (IEF_D * 2) + (((4 * j + q) ^ sw) & 15) * 16;
     // store of tile (a, b): row 16 a + m, columns 96 wave + 16 b + 4 q .. + 3 -> chunk 12 wave + 2 b + (q >> 1), half q & 1
+    // (mo, qo: the lane's m, q as the epilogue sees them -- made opaque there, so that hipcc recomputes these few-instruction
+    // offsets per tile instead of hoisting all 24 of them out of the projection loop into registers it then has to spill)
+    int mo = m, qo = q;
     auto img_off = [&](int a, int b) {
-        const int c = (RC_WCOLS / 8) * wave + 2 * b + (q >> 1);
-        return (16 * a + m) * (IEF_D * 2) + ((c & ~15) | ((c ^ sw) & 15)) * 16 + (q & 1) * 8;
+        const int c = (RC_WCOLS / 8) * wave + 2 * b + (qo >> 1);
+        return (16 * a + mo) * (IEF_D * 2) + ((c & ~15) | ((c ^ mo) & 15)) * 16 + (qo & 1) * 8;
     };
-    char* park = lds + RC_IMG_BYTES + wave * RC_PARK_BYTES + lane * 8;      // tile (a, b) of pass 0: + (a * RC_NBP + b) * 512
+    char* park = lds + RC_IMG_BYTES + wave * RC_PARK_BYTES + lane * 8;      // tile (a, b) of pass pp: + ((pp * 4 + a) * RC_NBP + b) * 512
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -156,23 +167,31 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
         const bool first = (g & 1) == 0;            // h = relu(z W1^T + b1); else z <- z - lambda (h W2^T + b2)
 #pragma unroll
         for (int pass = 0; pass < RC_NPASS; ++pass) {
-            // ring position of the pass's piece i: (i + 3 pass) % 6 -- a pass is 75 pieces = 3 mod 6, a projection 150 = 0 mod 6
+            // ring position of the pass's piece i: (i + pass x PASS_PIECES) % DEPTH (two passes: a pass is 75 pieces = 3 mod 6, a
+            // projection 150 = 0 mod 6; three passes: 50 = 0 mod 10)
+            constexpr int kRingOff = 0;
+            const int ring_off = (pass * RC_PASS_PIECES) % RC_DEPTH;
             f32x4 acc[4][RC_NBP];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < RC_NBP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int k4 = 0; k4 < RC_KT / 4; ++k4) {
+#if RC_KUNROLL == RC_KT
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+#else
+#pragma unroll 1
+#endif
+            for (int k4 = 0; k4 < RC_KT / RC_KUNROLL; ++k4) {
+#pragma unroll
+                for (int jj = 0; jj < RC_KUNROLL; ++jj) {
+                    const int j = jj & 3, k4q = (RC_KUNROLL == RC_KT) ? (jj >> 2) : k4;      // kt = 4 k4q + j
                     f32x4 ga[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) ga[a] = *(const f32x4*)(lds + rd[j] + a * (16 * IEF_D * 2) + k4 * 256);
+                    for (int a = 0; a < 4; ++a) ga[a] = *(const f32x4*)(lds + rd[j] + a * (16 * IEF_D * 2) + k4q * 256);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int b = 0; b < RC_NBP; ++b) {
-                        const int ri = (j * RC_NBP + b + RC_NBP * pass) % RC_DEPTH;      // 12 pieces per iteration = 0 mod 6
+                        const int ri = (jj * RC_NBP + b + ring_off + kRingOff) % RC_DEPTH;      // the iteration's pieces = 0 mod DEPTH
                         const f32x4 w = rg[ri];
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
@@ -185,11 +204,12 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                 }
             }
 
-            // ---- the pass's epilogue; its three bias pieces are the next three of the ring
+            // ---- the pass's epilogue; its bias pieces are the next ones of the ring
+            asm volatile("" : "+v"(mo), "+v"(qo));
             f32x4 bias[RC_NBP];
 #pragma unroll
             for (int b = 0; b < RC_NBP; ++b) {
-                const int ri = (RC_KT * RC_NBP + b + RC_NBP * pass) % RC_DEPTH;
+                const int ri = (RC_KT * RC_NBP + b + ring_off) % RC_DEPTH;
                 bias[b] = rg[ri];
                 rg[ri] = RC_LOAD(p + RC_DEPTH);
                 ++p;
@@ -203,10 +223,13 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                         f32x4 v = acc[a][b] + bias[b];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
-                        if (pass == 0) *(bf16x4_t*)(park + (a * RC_NBP + b) * 512) = to_bf16x4(v);      // waits for the image in the wave's own park
+                        if (pass < RC_NPASS - 1)      // the image is still being read: the tile waits in the wave's own park
+                            *(bf16x4_t*)(park + ((pass * 4 + a) * RC_NBP + b) * 512) = to_bf16x4(v);
                         else {
-                            *(bf16x4_t*)(lds + img_off(a, b)) = *(const bf16x4_t*)(park + (a * RC_NBP + b) * 512);
-                            *(bf16x4_t*)(lds + img_off(a, RC_NBP + b)) = to_bf16x4(v);
+#pragma unroll
+                            for (int pp = 0; pp < RC_NPASS - 1; ++pp)
+                                *(bf16x4_t*)(lds + img_off(a, RC_NBP * pp + b)) = *(const bf16x4_t*)(park + ((pp * 4 + a) * RC_NBP + b) * 512);
+                            *(bf16x4_t*)(lds + img_off(a, RC_NBP * pass + b)) = to_bf16x4(v);
                         }
                     }
             } else {
@@ -219,8 +242,9 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
 #pragma unroll
                         for (int e = 0; e < 4; ++e) z[a][bb][e] = __builtin_fmaf(-lambda, v[e], z[a][bb][e]);
                         if (pass == RC_NPASS - 1) {       // bf16(z) -> image for the next step (after the last step nobody reads it)
-                            *(bf16x4_t*)(lds + img_off(a, b)) = to_bf16x4(z[a][b]);
-                            *(bf16x4_t*)(lds + img_off(a, bb)) = to_bf16x4(z[a][bb]);
+#pragma unroll
+                            for (int pp = 0; pp < RC_NPASS; ++pp)
+                                *(bf16x4_t*)(lds + img_off(a, RC_NBP * pp + b)) = to_bf16x4(z[a][RC_NBP * pp + b]);
                         }
                     }
             }
