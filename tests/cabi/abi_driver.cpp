@@ -92,6 +92,29 @@ int main(int argc, char** argv) {
         fprintf(stderr, "small workspace was not refused\n");
         return 4;
     }
+    // whole videos (iefvad_forward_videos): the B chunk blocks re-read as B videos of T rows each plus, from the same rows, one
+    // short video -- every full chunk must score exactly as in the dense forward (same chunk content, row-independent tail;
+    // bit for bit in the F32 and BF16 modes, which is what this driver is run in for B = 2 and B = 64)
+    {
+        std::vector<int32_t> lens((size_t)B, T);
+        lens.back() = 100;                               // the last chunk's first 100 rows as a short video
+        const size_t rows = (size_t)(B - 1) * T + 100;
+        float *vl = nullptr, *vwi = nullptr, *vwe = nullptr;
+        HIPCK(hipMalloc((void**)&vl, rows * 4)); HIPCK(hipMalloc((void**)&vwi, rows * 4)); HIPCK(hipMalloc((void**)&vwe, rows * 4));
+        const size_t vws = iefvad_videos_workspace_bytes(h, lens.data(), B);
+        if (vws == 0 || vws > wsb) { fprintf(stderr, "videos workspace %zu vs %zu\n", vws, wsb); return 6; }
+        ABICK(iefvad_forward_videos(h, img, ev, IEFVAD_IN_F32, lens.data(), B, 1, ws, wsb, vl, vwi, vwe, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        std::vector<float> hv(rows);
+        HIPCK(hipMemcpy(hv.data(), vl, rows * 4, hipMemcpyDeviceToHost));
+        if ((compute == IEFVAD_COMPUTE_F32 || compute == IEFVAD_COMPUTE_BF16) && B > 1 &&
+            memcmp(hv.data(), hl.data(), (size_t)(B - 1) * T * 4) != 0) { fprintf(stderr, "forward_videos differs from the dense forward\n"); return 6; }
+        for (size_t i = 0; i < rows; ++i)
+            if (!(hv[i] == hv[i])) { fprintf(stderr, "forward_videos produced a NaN at row %zu\n", i); return 6; }
+        lens[0] = 0;
+        if (iefvad_forward_videos(h, img, ev, IEFVAD_IN_F32, lens.data(), B, 1, ws, wsb, vl, vwi, vwe, stream) == 0) { fprintf(stderr, "a zero-length video was accepted\n"); return 6; }
+        (void)hipFree(vl); (void)hipFree(vwi); (void)hipFree(vwe);
+    }
     // the score gather with no torch in the process: librccl is bound from the system ROCm by dlopen; a
     // one-rank communicator exercises id -> init -> count -> all-gather (equal counts) -> the unequal-count bookkeeping
     {
@@ -120,7 +143,7 @@ int main(int argc, char** argv) {
         iefvad_comm_destroy(comm);
         (void)hipFree(gathered);
     }
-    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, gather through librccl OK\n", B, L, K, st.total_ms, st.gemm_launches);
+    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK\n", B, L, K, st.total_ms, st.gemm_launches);
     iefvad_destroy(h);
     (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);
     return 0;
