@@ -26,6 +26,7 @@
 #include "heads_fused_bf16.h"
 #include "outproj_ln_bf16.h"
 #include "refine_chain_bf16.h"
+#include "outproj_ln_chain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
 
@@ -58,6 +59,8 @@ struct iefvad_handle {
     bool weights_set;
     bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
     bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
+    bool ol_v1;            // IEFVAD_OL_V1=1: bf16 mode's fused out_proj + LayerNorm on the first design (outproj_ln_bf16.h) instead of the chain-style one
+    char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
     bool no_chain;         // IEFVAD_NO_CHAIN=1: bf16 mode runs the refinement as 2K projection launches + the scorer kernel
     char* chain_stream;    // bf16 mode: the refinement weights in the chain kernel's per-wave piece order (refine_chain_bf16.h)
     float* arena;          // one allocation holding every repacked weight
@@ -156,6 +159,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     { const char* v = getenv("IEFVAD_NO_HEADS_FUSION"); h->no_heads_fusion = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_LN_FUSION"); h->no_ln_fusion = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_CHAIN"); h->no_chain = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_OL_V1"); h->ol_v1 = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -175,6 +179,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_refine_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RC_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OC_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
@@ -208,6 +215,9 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->arena_b) (void)hipFree(h->arena_b);
     if (h->chain_stream) (void)hipFree(h->chain_stream);
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l)
+            if (h->oproj_stream[m][l]) (void)hipFree(h->oproj_stream[m][l]);
     if (h->arena_s) (void)hipFree(h->arena_s);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
@@ -322,6 +332,12 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
             if (int rc = conv(&h->ref_w1b[k], h->ref_w1[k], DD)) return rc;
             if (int rc = conv(&h->ref_w2b[k], h->ref_w2[k], DD)) return rc;
         }
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < L; ++l) {
+                if (!h->oproj_stream[m][l]) HIP_TRY(hipMalloc((void**)&h->oproj_stream[m][l], wstream_bytes()));
+                hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(256), dim3(256), 0, stream, h->out_wb[m][l], h->oproj_stream[m][l]);
+                HIP_TRY(hipGetLastError());
+            }
         if (K > 0) {
             // the same bf16 matrices (and the fp32 biases) once more, in the chain kernel's per-wave piece order
             if (!h->chain_stream) HIP_TRY(hipMalloc((void**)&h->chain_stream, chain_stream_bytes(K)));
@@ -791,6 +807,32 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 
             // out_proj + residual + LayerNorm(s) in one row-owning kernel (bf16 mode, full grids): outproj_ln_bf16.h
             const bool ln_fused = bf && !h->no_ln_fusion && rows % OL_BM == 0 && (rows / OL_BM) * 2 >= 256;
+            if (ln_fused && !h->ol_v1) {
+                // second design: 64-row blocks on the refinement chain's structure (outproj_ln_chain_bf16.h); same bits
+                OutLnChainArgs oa;
+                memset(&oa, 0, sizeof(oa));
+                for (int m = 0; m < 2; ++m) {
+                    OutLnChainProblem& q = oa.p[m];
+                    q.A = attb[m]; q.stream = h->oproj_stream[m][l]; q.bias = h->out_b[m][l]; q.R = cur[m];
+                    q.g1 = h->norm_w[m][l]; q.b1 = h->norm_b[m][l];
+                    if (l == L - 1) { q.g2 = h->whiten_w[m]; q.b2 = h->whiten_b[m]; }
+                    q.y = (l < L - 1) ? xbuf[m] : nullptr;      // fp32 rows are only the next layer's residual
+                    q.yb = xb[m];
+                }
+                oa.M = rows; oa.eps = 1e-5f; oa.wave_stride = (unsigned)wstream_wave_stride_bytes();
+                { static const int st = [] { const char* v = getenv("IEFVAD_OL_STAGGER"); return v ? atoi(v) : 0; }(); oa.stagger = st; }
+#ifdef OC_DIAG
+                { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_OC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); oa.diag = dg; }
+#endif
+                e = tm.begin(ST_OUT);
+                hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
+                tm.end(e);
+                tm.gemm_launches += 1;
+                HIP_TRY(hipGetLastError());
+                cur[0] = xbuf[0];
+                cur[1] = xbuf[1];
+                continue;
+            }
             if (ln_fused) {
                 OutLnArgs oa;
                 memset(&oa, 0, sizeof(oa));

@@ -56,6 +56,57 @@ __device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const floa
     }
 }
 
+// ln_row on R rows of one wave at a time: the same operations per row in the same order, with the R independent reduction
+// chains (two 6-step shuffle trees per row, each step a dependent LDS-crossbar round trip) interleaved.  For callers with few
+// resident waves (outproj_ln_chain_bf16.h: two per SIMD), where one row after the other costs ~1,700 cycles per LayerNorm.
+template <int R>
+__device__ __forceinline__ void ln_rows(f32x4 (&v)[R][3], const float* g, const float* b, int lane, float eps) {
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s[r] += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    float ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float mean = s[r] * (1.0f / IEF_D);
+        ss[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[r][j][e] - mean;
+                v[r][j][e] = d;
+                ss[r] += d * d;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) ss[r] += __shfl_xor(ss[r], o, 64);
+    f32x4 gv[3], bv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gv[j] = *(const f32x4*)(g + 4 * lane + 256 * j);
+        bv[j] = *(const f32x4*)(b + 4 * lane + 256 * j);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float var = ss[r] * (1.0f / IEF_D);
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[r][j][e] = v[r][j][e] * rstd * gv[j][e] + bv[j][e];
+    }
+}
+
 __global__ __launch_bounds__(256) void iefvad_layernorm_kernel(LnArgs a) {
     const int mod = blockIdx.y;
     const int lane = threadIdx.x & 63;

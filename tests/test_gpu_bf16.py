@@ -104,11 +104,13 @@ def test_bf16_scores_mode_and_microbatch_bit_identical():
     assert (b["w_i_mean"] - a["w_i"].mean(-1)).abs().max().item() < 1e-6
 
 
-@pytest.mark.parametrize("outputs,overflow,L", [("full", False, 2), ("scores", False, 2), ("full", True, 2), ("full", False, 3)])
-def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypatch, outputs, overflow, L):
+@pytest.mark.parametrize("outputs,overflow,L,ol_v1", [("full", False, 2, False), ("scores", False, 2, False), ("full", True, 2, False),
+                                                       ("full", False, 3, False), ("full", False, 3, True), ("scores", False, 2, True)])
+def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypatch, outputs, overflow, L, ol_v1):
     """bf16 mode runs the heads of both modalities and the fusion as ONE kernel once a micro-batch fills the chip
-    (csrc/heads_fused_bf16.h; >= 22 chunks), and out_proj + residual + LayerNorm(s) as one row-owning kernel
-    (csrc/outproj_ln_bf16.h; >= 64 chunks).  Same k order, same LayerNorm / fusion code: every output must equal the
+    (csrc/heads_fused_bf16.h; >= 22 chunks), and out_proj + residual + LayerNorm(s) as one row-owning kernel (>= 64 chunks:
+    csrc/outproj_ln_chain_bf16.h, 64-row blocks on the refinement chain's structure; `ol_v1`: the first design,
+    csrc/outproj_ln_bf16.h, IEFVAD_OL_V1=1).  Same k order, same LayerNorm / fusion code: every output must equal the
     unfused path bit for bit (IEFVAD_NO_HEADS_FUSION=1, IEFVAD_NO_LN_FUSION=1 at model creation), the row means of the
     weights to fp32 rounding (their partial sums are combined in another order).  `overflow`: a log-variance column that
     overflows the literal formula (inf / inf = NaN, imf_vad.py:135-142), without refinement steps so that the NaN stays in
@@ -124,7 +126,10 @@ def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypat
     img, ev = synth.make_inputs(33, 64)
     ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
     with torch.no_grad():
+        if ol_v1:
+            monkeypatch.setenv("IEFVAD_OL_V1", "1")
         fused = make_model(L, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
+        monkeypatch.delenv("IEFVAD_OL_V1", raising=False)
         monkeypatch.setenv("IEFVAD_NO_HEADS_FUSION", "1")
         monkeypatch.setenv("IEFVAD_NO_LN_FUSION", "1")
         plain = make_model(L, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
