@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_chain_bf16_kernel(Ou
         const float* rp = P.R + (size_t)(m0 + 32 * (half_) + 4 * wave + u) * IEF_D + 4 * lane;             \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) res[u][j] = *(const f32x4*)(rp + 256 * j);           \
     }
-    OC_FETCH_RES(0)
+    OC_FETCH_RES(0)       // (requested after the image barrier instead: image ready 20 k -> 13 k cycles, main loop 20 k -> 27 k: the
+                          // 96 KB take their time wherever they sit in the wave's in-order queue; profiles/r03_outproj_chain_phase_stamps.log)
     // bias and the LayerNorms' affine terms go to LDS once per workgroup (15 KB behind the park): ln_row loads them from global
     // memory per row -- six dependent L2 round trips per row that two resident waves per SIMD cannot hide (3.4 k cycles per
     // row in the first build) -- and keeping them in registers (60) beside two residual sets made hipcc spill
