@@ -34,7 +34,7 @@ for mode in bf16 bf16x6; do
   python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_$mode" "$O/pmc_fetch_$mode" "$O/pmc_write_$mode" > "$O/pmc_summary_$mode.txt" 2>&1
 done
 SRC="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024"
-K="iefvad_gemm_bf16_w256_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_bf16_kernel"
+K="iefvad_gemm_bf16_w256_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_chain_bf16_kernel"
 # algorithmic bytes of the six projection launches of a 262,144-row pass (bf16 mode, outputs=scores), KB per row, both modalities:
 # in_proj x2: read 3 (bf16 A), write 9 (bf16 q|k|v); out_proj+LN x2: read 3 + 6 (fp32 residual), write 6 fp32 + 3 bf16 (layer 0) / 3 bf16
 # (layer 1); heads+fusion: read 3, write 3 (fp32 z) + 0.1; refinement chain: read 3 (z), write 0.004
