@@ -22,20 +22,29 @@ struct AttnBArgs {
     const bf16_t* qkv[2];   // [N, 2304] bf16 per modality: q | k | v, head h at columns h*96
     bf16_t* out[2];         // [N, 768] bf16 per modality
     int nchunks;            // chunks per modality in this launch
+    const RaggedChunk* chunks;   // *_rows_kernel: row-compressed chunks (common.h); row r of the window = row min(r, valid)
 };
 
 #define ATTB_KROW 104   // K image row length in bf16 elements (208 B = 13 x 16 B)
 #define ATTB_VROW 96    // V image row length in bf16 elements (192 B)
 #define ATTB_LDS_BYTES (IEF_T * ATTB_KROW * 2)   // 53,248 B, V image (49,152 B) reuses it
 
-__global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs args) {
-    __shared__ __attribute__((aligned(16))) bf16_t kv[IEF_T * ATTB_KROW];
+template <bool RG>
+__device__ __forceinline__ void attention_bf16_body(const AttnBArgs& args, bf16_t* kv) {
     // grid (8 heads, 2 query halves, chunks x modalities): the two halves of a (chunk, head) are 8 apart in linear
     // block order, i.e. dispatched back to back onto the SAME XCD (round-robin over 8), so the second half's K / V
     // re-read hits that XCD's L2 instead of HBM
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
-    const bf16_t* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
-    bf16_t* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    int row0 = chunk * IEF_T, last = IEF_T - 1;      // first row of the window in the row set, last distinct row of the window
+    if constexpr (RG) {
+        const RaggedChunk c = args.chunks[chunk];
+        row0 = c.enc_row;
+        last = ragged_rows(c.valid) - 1;
+        if (qhalf * 128 > last) return;              // every query of this half is a pad row: nobody reads its output
+    }
+#define ATTB_ROW(r) (RG ? ((r) < last ? (r) : last) : (r))
+    const bf16_t* qkv = args.qkv[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
+    bf16_t* out = args.out[mod] + (size_t)row0 * IEF_D + head * IEF_DH;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
     // Q fragment (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
     bf16x8 q[6];
     {
-        const bf16_t* qp = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 8 * h;
+        const bf16_t* qp = qkv + (size_t)ATTB_ROW(q0 + i) * (3 * IEF_D) + 8 * h;
 #pragma unroll
         for (int s = 0; s < 6; ++s) q[s] = *(const bf16x8*)(qp + 16 * s);
     }
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
     for (int j = 0; j < 12; ++j) {
         const int c = t + 256 * j;
         const int row = c / 12, ch = c - row * 12;
-        *(bf16x8*)(kv + row * ATTB_KROW + ch * 8) = *(const bf16x8*)(qkv + (size_t)row * (3 * IEF_D) + IEF_D + ch * 8);
+        *(bf16x8*)(kv + row * ATTB_KROW + ch * 8) = *(const bf16x8*)(qkv + (size_t)ATTB_ROW(row) * (3 * IEF_D) + IEF_D + ch * 8);
     }
     __syncthreads();
 
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
     for (int j = 0; j < 12; ++j) {
         const int c = t + 256 * j;
         const int row = c / 12, ch = c - row * 12;
-        vstage[j] = *(const bf16x8*)(qkv + (size_t)row * (3 * IEF_D) + 2 * IEF_D + ch * 8);
+        vstage[j] = *(const bf16x8*)(qkv + (size_t)ATTB_ROW(row) * (3 * IEF_D) + 2 * IEF_D + ch * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -148,6 +157,18 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(size_t)qrow * IEF_D + dt * 32 + i] = (bf16_t)o[dt][r];
+            if (!RG || qrow <= last) out[(size_t)qrow * IEF_D + dt * 32 + i] = (bf16_t)o[dt][r];
         }
+#undef ATTB_ROW
+}
+
+__global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_kernel(AttnBArgs args) {
+    __shared__ __attribute__((aligned(16))) bf16_t kv[IEF_T * ATTB_KROW];
+    attention_bf16_body<false>(args, kv);
+}
+
+// row-compressed chunks of a whole-video pass (ragged.h)
+__global__ __launch_bounds__(256, 2) void iefvad_attention_bf16_rows_kernel(AttnBArgs args) {
+    __shared__ __attribute__((aligned(16))) bf16_t kv[IEF_T * ATTB_KROW];
+    attention_bf16_body<true>(args, kv);
 }

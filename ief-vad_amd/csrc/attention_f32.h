@@ -23,6 +23,7 @@ struct AttnArgs {
     int nchunks;           // chunks per modality in this launch
     float* amax[2];        // fp16x3 mode (attention_split.h only): running max |out| per modality, nullable
     const float* amax_in[2];   // fp16x3 attention: running max |q k v| of the input tensor (operand scale)
+    const RaggedChunk* chunks; // *_rows_kernel: row-compressed chunks (common.h); row r of the window = row min(r, valid)
 };
 
 #define ATT_LDK 100
@@ -34,14 +35,22 @@ struct AttnArgs {
 // tile i, the global loads of tile i+1 are in flight into registers, and they are written to the other LDS
 // buffer after the MFMAs (issue-early / write-late staging).  51 KB of LDS and <= 256 VGPRs let two workgroups
 // share a CU, so one workgroup's softmax and barriers hide under the other's matrix work.
-__global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs args) {
-    __shared__ __attribute__((aligned(16))) float kv[2 * ATT_TILE];
+template <bool RG>
+__device__ __forceinline__ void attention_f32_body(const AttnArgs& args, float* kv) {
     // grid (8 heads, 2 query halves, chunks x modalities): the two halves of a (chunk, head) are 8 apart in linear
     // block order, i.e. dispatched back to back onto the SAME XCD (round-robin over 8), so the second half's K / V
     // re-read hits that XCD's L2 instead of HBM
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
-    const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
-    const size_t obase = (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    int row0 = chunk * IEF_T, last = IEF_T - 1;      // first row of the window in the row set, last distinct row of the window
+    if constexpr (RG) {
+        const RaggedChunk c = args.chunks[chunk];
+        row0 = c.enc_row;
+        last = ragged_rows(c.valid) - 1;
+        if (qhalf * 128 > last) return;              // every query of this half is a pad row: nobody reads its output
+    }
+#define ATT_ROW(r) (RG ? ((r) < last ? (r) : last) : (r))
+    const float* qkv = args.qkv[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
+    const size_t obase = (size_t)row0 * IEF_D + head * IEF_DH;
     float* out = args.out[mod] ? args.out[mod] + obase : nullptr;
     __bf16* outb = args.outb[mod] ? args.outb[mod] + obase : nullptr;
 
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs a
     // Q fragment: lane (i, h) holds Q[q0 + i][8s + 4h .. +3], s = 0..11 (B operand of K Q^T)
     f32x4 q[12];
     {
-        const float* qp = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 4 * h;
+        const float* qp = qkv + (size_t)ATT_ROW(q0 + i) * (3 * IEF_D) + 4 * h;
 #pragma unroll
         for (int s = 0; s < 12; ++s) q[s] = *(const f32x4*)(qp + 8 * s);
     }
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs a
     // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
 #define ATT_LOAD(ti)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
-        stg[j] = *(const f32x4*)(qkv + (size_t)(((ti) & 3) * ATT_TK + srow[j]) * (3 * IEF_D) +                \
+        stg[j] = *(const f32x4*)(qkv + (size_t)ATT_ROW(((ti) & 3) * ATT_TK + srow[j]) * (3 * IEF_D) +       \
                                  ((ti) < 4 ? IEF_D : 2 * IEF_D) + sch[j] * 4);
 #define ATT_WRITE(buf)                                                                                        \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
@@ -163,7 +172,20 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (RG && qrow > last) continue;
             if (outb) outb[(size_t)qrow * IEF_D + dt * 32 + i] = (__bf16)o[dt][r];
             else out[(size_t)qrow * IEF_D + dt * 32 + i] = o[dt][r];
         }
+#undef ATT_ROW
+}
+
+__global__ __launch_bounds__(256, 2) void iefvad_attention_f32_kernel(AttnArgs args) {
+    __shared__ __attribute__((aligned(16))) float kv[2 * ATT_TILE];
+    attention_f32_body<false>(args, kv);
+}
+
+// row-compressed chunks of a whole-video pass (ragged.h)
+__global__ __launch_bounds__(256, 2) void iefvad_attention_f32_rows_kernel(AttnArgs args) {
+    __shared__ __attribute__((aligned(16))) float kv[2 * ATT_TILE];
+    attention_f32_body<true>(args, kv);
 }

@@ -61,13 +61,21 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (
     if constexpr (!F16) { ATS_MFMA(xp[NP - 1], yp[0], c); ATS_MFMA(xp[0], yp[NP - 1], c); ATS_MFMA(xp[1], yp[1], c); } \
     ATS_MFMA(xp[1], yp[0], c); ATS_MFMA(xp[0], yp[1], c); ATS_MFMA(xp[0], yp[0], c)
 
-template <bool F16>
+template <bool F16, bool RG = false>
 __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs) {
     constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
-    const float* qkv = args.qkv[mod] + (size_t)chunk * IEF_T * (3 * IEF_D) + head * IEF_DH;
-    float* out = args.out[mod] + (size_t)chunk * IEF_T * IEF_D + head * IEF_DH;
+    int row0 = chunk * IEF_T, last = IEF_T - 1;      // first row of the window in the row set, last distinct row of the window
+    if constexpr (RG) {
+        const RaggedChunk c = args.chunks[chunk];
+        row0 = c.enc_row;
+        last = ragged_rows(c.valid) - 1;
+        if (qhalf * 128 > last) return;              // every query of this half is a pad row: nobody reads its output
+    }
+#define ATS_ROW(r) (RG ? ((r) < last ? (r) : last) : (r))
+    const float* qkv = args.qkv[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
+    float* out = args.out[mod] + (size_t)row0 * IEF_D + head * IEF_DH;
     float qs = 1.0f, s_inv2 = 1.0f, o_inv = 1.0f;      // fp16x3: operand scale of q / k / v, score and output rescale
     constexpr float kPScale = 8192.0f;                 // P <= 1 -> 2^13
     if constexpr (F16) {
@@ -85,12 +93,13 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     // staging map: a 64-row x 24-chunk (4 floats) tile; thread t moves rows (t >> 3) + 32 (j & 1), chunks (t & 7) + 8 (j >> 1),
     // j = 0..5: eight lanes cover one 128-byte line, and every offset is a constant added to two per-thread bases
     const int srow0 = t >> 3, sch0 = t & 7;
-    const float* gsrc = qkv + (size_t)srow0 * (3 * IEF_D) + sch0 * 4;
+    const float* gsrc = qkv + (RG ? 0 : (size_t)srow0 * (3 * IEF_D)) + sch0 * 4;     // RG: the row is clamped per load
     f32x4 stg[6];
     // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
 #define ATS_LOAD(ti)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
-        stg[j] = *(const f32x4*)(gsrc + (size_t)(((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +          \
+        stg[j] = *(const f32x4*)(gsrc + (size_t)(RG ? ATS_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + srow0)         \
+                                                      : ((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +       \
                                  ((ti) < 4 ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
     // split the staged fp32 chunks and write the three bf16 plane images of tile ti into buffer `buf`
 #define ATS_WRITE(ti, buf)                                                                                    \
@@ -111,7 +120,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     // Q planes (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
     u32x4 qp[6][NP];
     {
-        const float* qptr = qkv + (size_t)(q0 + i) * (3 * IEF_D) + 8 * h;
+        const float* qptr = qkv + (size_t)ATS_ROW(q0 + i) * (3 * IEF_D) + 8 * h;
 #pragma unroll
         for (int s = 0; s < 6; ++s)
             split8<F16, NP>(*(const f32x4*)(qptr + 16 * s), *(const f32x4*)(qptr + 16 * s + 4), qp[s], qs);
@@ -219,7 +228,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float ov = F16 ? o[dt][r] * o_inv : o[dt][r];
-            out[(size_t)qrow * IEF_D + dt * 32 + i] = ov;
+            if (!RG || qrow <= last) out[(size_t)qrow * IEF_D + dt * 32 + i] = ov;
             if constexpr (F16) om = amax_fold(om, ov);
         }
     if constexpr (F16) {      // running max |out| for the out_proj operand scale
@@ -228,10 +237,17 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
 }
 #undef ATS_SIX
 #undef ATS_MFMA
+#undef ATS_ROW
 
 __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs args) {
     extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
     attention_split_body<false>(args, kvs);
+}
+
+// row-compressed chunks of a whole-video pass (ragged.h)
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_rows_kernel(AttnArgs args) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<false, true>(args, kvs);
 }
 
 // fp16x3

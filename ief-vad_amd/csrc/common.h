@@ -11,6 +11,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define IEF_H 8        // heads
 #define IEF_DH 96      // head dim
 
+// One 256-snippet chunk of a whole-video pass (ragged.h).  The encoder's row set holds the chunk at rows enc_row ..: either all
+// 256 rows (valid rows, then zero rows), or -- row-compressed -- the valid rows followed by ONE zero row standing for all
+// 256 - valid pad rows of the chunk: pad rows are identical in every layer (same input, row-wise projections, and attention
+// gives equal queries equal outputs), so every kernel that needs "row r of the chunk" reads row min(r, valid).
+struct RaggedChunk {
+    int src_row;   // first packed row of the chunk, relative to the pass's first packed row
+    int valid;     // 1..256 valid rows
+    int video;     // index of the video in the call (selects the NaN flag)
+    int enc_row;   // first row of the chunk in the encoder's row set
+};
+// rows the chunk occupies in a row-compressed set
+__host__ __device__ __forceinline__ int ragged_rows(int valid) { return valid < IEF_T ? valid + 1 : IEF_T; }
+
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap so that each
 // XCD walks a contiguous range of logical tile ids; bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

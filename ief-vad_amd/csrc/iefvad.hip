@@ -61,6 +61,7 @@ struct iefvad_handle {
     bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
     bool ol_v1;            // IEFVAD_OL_V1=1: bf16 mode's fused out_proj + LayerNorm on the first design (outproj_ln_bf16.h) instead of the chain-style one
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
+    bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
     bool no_chain;         // IEFVAD_NO_CHAIN=1: bf16 mode runs the refinement as 2K projection launches + the scorer kernel
     char* chain_stream;    // bf16 mode: the refinement weights in the chain kernel's per-wave piece order (refine_chain_bf16.h)
     float* arena;          // one allocation holding every repacked weight
@@ -160,6 +161,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     { const char* v = getenv("IEFVAD_NO_LN_FUSION"); h->no_ln_fusion = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_CHAIN"); h->no_chain = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_OL_V1"); h->ol_v1 = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_DENSE_ENCODER"); h->dense_encoder = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -648,6 +650,8 @@ struct RaggedPass {
     const RaggedChunk* d_chunks;     // device: the pass's chunks (src_row relative to the pass's first packed row)
     const int* d_flags;              // device: NaN flag per (video, modality); nullptr = no nan_to_num
     int valid_rows;                  // packed rows of the pass
+    int enc_used_rows;               // rows of the compressed set that belong to chunks
+    int enc_rows;                    // > 0: the encoder's row set is row-compressed (RaggedChunk, common.h) and has this many rows (a multiple of 256)
     float* logits;                   // packed outputs at the pass's first row, nullable
     float* w_i_mean;
     float* w_e_mean;
@@ -666,8 +670,9 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
     const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;   // imf_vad.py:134
     const float qscale = 1.0f / sqrtf((float)IEF_DH);
     {
-        int rows = nb * IEF_T;
-        const size_t R = (size_t)rows;
+        const bool enc_rows_mode = rg && rg->enc_rows > 0;       // row-compressed chunks: valid rows + one pad row each
+        int rows = enc_rows_mode ? rg->enc_rows : nb * IEF_T;
+        const size_t R = (size_t)nb * IEF_T;                     // region stride: the dense capacity
         // workspace regions, in units of R*768 floats: xin 0..2 | qkv 2..8 | att 8..10 | y 10..12 | x 12..14 | logits
         float* ws = (float*)workspace;
         float* xin[2] = {ws, ws + R * D};
@@ -704,6 +709,13 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         const char* pe = (const char*)pe_;
         if (rg) {
             // the chunker (tools.py:100-114) and the conditional nan_to_num (test.py:90-95) on the device: ragged.h
+            if (enc_rows_mode && rg->enc_used_rows < rows) {     // the zero rows that round the set up to whole 256-row tiles
+                const size_t o = (size_t)rg->enc_used_rows * D, n = (size_t)(rows - rg->enc_used_rows) * D;
+                for (int m = 0; m < 2; ++m) {
+                    HIP_TRY(hipMemsetAsync(xin[m] + o, 0, n * sizeof(float), stream));
+                    if (bf) HIP_TRY(hipMemsetAsync(xb[m] + o, 0, n * sizeof(bf16_t), stream));
+                }
+            }
             hipEvent_t e = tm.begin(ST_CAST);
 #define RAGGED_IN(T)                                                                                                        \
     do {                                                                                                                    \
@@ -712,7 +724,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                                (const T*)rg->ev_rows, rg->d_chunks, (int*)rg->d_flags);                                     \
         hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,         \
                            (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], bf ? xb[0] : (bf16_t*)nullptr,  \
-                           bf ? xb[1] : (bf16_t*)nullptr);                                                                  \
+                           bf ? xb[1] : (bf16_t*)nullptr, enc_rows_mode ? 0 : IEF_T);                                       \
     } while (0)
             if (in_dtype == IEFVAD_IN_F32) RAGGED_IN(float);
             else if (in_dtype == IEFVAD_IN_F16) RAGGED_IN(__half);
@@ -786,19 +798,26 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 AttnBArgs ab;
                 for (int m = 0; m < 2; ++m) { ab.qkv[m] = qkvb[m]; ab.out[m] = attb[m]; }
                 ab.nchunks = nb;
-                hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
+                ab.chunks = enc_rows_mode ? rg->d_chunks : nullptr;
+                if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_bf16_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
+                else hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
             } else {
                 AttnArgs aa;
                 memset(&aa, 0, sizeof(aa));
                 for (int m = 0; m < 2; ++m) { aa.qkv[m] = qkv[m]; aa.out[m] = att[m]; }
                 aa.nchunks = nb;
+                aa.chunks = enc_rows_mode ? rg->d_chunks : nullptr;
                 // bf16x6: the split attention kernel goes with the split projections (same batch-size rule), so a small
                 // batch is computed exactly as in the f32 mode
                 for (int m = 0; m < 2; ++m) { aa.amax[m] = am_att(l, m); aa.amax_in[m] = am_qkv(l, m); }
                 if (f16mb)
                     hipLaunchKernelGGL(iefvad_attention_split_f16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
+                else if (splitmb && enc_rows_mode)
+                    hipLaunchKernelGGL(iefvad_attention_split_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
                 else if (splitmb)
                     hipLaunchKernelGGL(iefvad_attention_split_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), ATS_LDS_BYTES, stream, aa);
+                else if (enc_rows_mode)
+                    hipLaunchKernelGGL(iefvad_attention_f32_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
                 else
                     hipLaunchKernelGGL(iefvad_attention_f32_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, aa);
             }
@@ -884,14 +903,15 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             cur[1] = xbuf[1];
         }
 
-        // Ragged pass: everything behind the encoder is row-wise (imf_vad.py:125-150) and the reference slices the pad rows away
-        // (test.py:121), so the valid rows of the last LayerNorm's output are gathered (packed order, padded with zero rows
-        // to whole 256-row tiles) and `rows` shrinks to that count from here on.  fp16x3 keeps whole chunks: its operand
-        // scales are per chunk.  The compact operands live in the attention-output region, dead by now.
+        // Ragged pass with whole chunks in the encoder (IEFVAD_DENSE_ENCODER=1): everything behind the encoder is row-wise
+        // (imf_vad.py:125-150) and the reference slices the pad rows away (test.py:121), so the valid rows of the last
+        // LayerNorm's output are gathered (packed order, padded with zero rows to whole 256-row tiles) and `rows` shrinks to
+        // that count from here on.  fp16x3 keeps whole chunks: its operand scales are per chunk.  The compact operands live in
+        // the attention-output region, dead by now.  (Row-compressed chunks, the default: the tail runs on the encoder's row set.)
         const float* xt[2] = {xbuf[0], xbuf[1]};      // the tail's fp32 / bf16 A operands
         const bf16_t* xtb[2] = {xb[0], xb[1]};
         bool compacted = false;
-        if (rg && c.compute != IEFVAD_COMPUTE_FP16X3) {
+        if (rg && !enc_rows_mode && c.compute != IEFVAD_COMPUTE_FP16X3) {
             const int mc = (rg->valid_rows + 255) / 256 * 256;
             if (mc < rows) {
                 CompactArgs ca;
@@ -1152,19 +1172,23 @@ static int forward_videos_impl(iefvad_handle* h, const void* img_rows, const voi
     }
     RaggedChunk* hc = (RaggedChunk*)mr.host[slot];
     const int mb = micro_batch(h);
+    // fp16x3 carries one operand scale per 256-row chunk of the row set: it keeps whole chunks
+    const bool enc_rows_mode = !h->dense_encoder && h->cfg.compute != IEFVAD_COMPUTE_FP16X3;
     {
-        // chunk table; src_row is relative to the first packed row of the chunk's PASS (passes are runs of <= mb chunks)
+        // chunk table; src_row and enc_row are relative to the chunk's PASS (passes are runs of <= mb chunks)
         long long row = 0, pass_row0 = 0;
         long long ci = 0;
+        int enc = 0;
         for (int v = 0; v < nvideos; ++v) {
             const int n = lengths[v], nch = video_chunks(n);
             for (int j = 0; j < nch; ++j, ++ci) {
-                if (ci % mb == 0) pass_row0 = row;
+                if (ci % mb == 0) { pass_row0 = row; enc = 0; }
                 const int valid = (n - j * IEF_T) < IEF_T ? (n - j * IEF_T) : IEF_T;
                 hc[ci].src_row = (int)(row - pass_row0);
                 hc[ci].valid = valid;
                 hc[ci].video = v;
-                hc[ci].pad_ = 0;
+                hc[ci].enc_row = enc;
+                enc += enc_rows_mode ? ragged_rows(valid) : IEF_T;
                 row += valid;
             }
         }
@@ -1189,6 +1213,11 @@ static int forward_videos_impl(iefvad_handle* h, const void* img_rows, const voi
         rg.d_chunks = dc + c0;
         rg.d_flags = dflags;
         rg.valid_rows = (int)vrows;
+        rg.enc_used_rows = rg.enc_rows = 0;
+        if (enc_rows_mode) {
+            rg.enc_used_rows = hc[c0 + nb - 1].enc_row + ragged_rows(hc[c0 + nb - 1].valid);
+            rg.enc_rows = (rg.enc_used_rows + IEF_T - 1) / IEF_T * IEF_T;        // <= nb * 256
+        }
         rg.logits = logits + row0;
         rg.w_i_mean = w_i_mean ? w_i_mean + row0 : nullptr;
         rg.w_e_mean = w_e_mean ? w_e_mean + row0 : nullptr;

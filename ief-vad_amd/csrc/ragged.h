@@ -11,22 +11,19 @@
 //     len % 256 == 0 video, whose rows test.py:121 slices away, is not built), applies torch.nan_to_num(nan=0.0) -- NaN -> 0,
 //     +-inf -> the source dtype's max / min -- to the videos whose flag is set, widens to fp32 (imf_vad.py:41-42) and, in
 //     bf16 mode, writes the bf16 operand copy as well;
-//   * the encoder runs on whole chunks (attention is over the full zero-padded window, imf_vad.py:115: unmasked by design);
-//   * iefvad_compact_rows_kernel then gathers the valid rows of the last LayerNorm's output, and everything behind the
-//     encoder (imf_vad.py:125-150: heads, fusion, K refinement steps, scorer -- 56 % of the FLOPs, all row-wise) runs on
-//     those rows only: same kernels, row-independent arithmetic, so the kept rows' results do not change.
+//   * attention is over the full zero-padded window (imf_vad.py:115: unmasked by design), but the pad rows of a chunk are
+//     identical in every layer, so the encoder's row set holds ONE of them per chunk (RaggedChunk, common.h): the projections
+//     and LayerNorms run on valid + 1 rows per chunk, the attention kernels read row min(r, valid) for row r of the window
+//     (attention_*.h, *_rows_kernel) -- every product and every sum of the dense computation, from fewer distinct rows;
+//   * everything behind the encoder (imf_vad.py:125-150: heads, fusion, K refinement steps, scorer -- 56 % of the FLOPs, all
+//     row-wise) runs on the same row set; iefvad_rows_out_kernel picks the valid rows' results (test.py:121).
+//   fp16x3 (per-chunk operand scales) and IEFVAD_DENSE_ENCODER=1 keep whole chunks in the encoder;
+//   iefvad_compact_rows_kernel then gathers the valid rows of the last LayerNorm's output for the tail.
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include "common.h"
 #include "rowops.h"
-
-struct RaggedChunk {
-    int src_row;   // first packed row of the chunk, relative to the pass's first packed row
-    int valid;     // 1..256 valid rows
-    int video;     // index of the video in the call (selects the NaN flag)
-    int pad_;
-};
 
 template <typename T> struct RaggedLimits;
 template <> struct RaggedLimits<float> { static __device__ float max() { return 3.40282347e38f; } };
@@ -40,7 +37,17 @@ __global__ __launch_bounds__(256) void iefvad_nanflag_kernel(const T* img, const
     const T* src = (blockIdx.y ? ev : img) + (size_t)c.src_row * IEF_D;
     const int n = c.valid * IEF_D;
     bool bad = false;
-    for (int i = threadIdx.x * 4; i < n; i += 256 * 4) {
+    int i = threadIdx.x * 4;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {          // n is a multiple of 768: four 16-byte (8-byte) loads in flight per lane
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * u + e] = (float)src[i + 1024 * u + e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bad |= (v[e] != v[e]);
+    }
+    for (; i < n; i += 1024) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float v = (float)src[i + e];
@@ -51,36 +58,54 @@ __global__ __launch_bounds__(256) void iefvad_nanflag_kernel(const T* img, const
 }
 
 // one workgroup per (chunk, modality): valid rows from the packed input (fixed up if the video's flag is set), zeros behind them
+// (nrows = 256: whole chunks; nrows = 0: row-compressed, one zero row)
 template <typename T>
 __global__ __launch_bounds__(256) void iefvad_scatter_rows_kernel(const T* img, const T* ev, const RaggedChunk* chunks, const int* flags,
-                                                                  float* out0, float* out1, __bf16* ob0, __bf16* ob1) {
+                                                                  float* out0, float* out1, __bf16* ob0, __bf16* ob1, int nrows) {
     const RaggedChunk c = chunks[blockIdx.x];
     const int m = blockIdx.y;
     const T* src = (m ? ev : img) + (size_t)c.src_row * IEF_D;
-    float* out = (m ? out1 : out0) + (size_t)blockIdx.x * IEF_T * IEF_D;
+    float* out = (m ? out1 : out0) + (size_t)c.enc_row * IEF_D;
     __bf16* ob = m ? ob1 : ob0;
-    if (ob) ob += (size_t)blockIdx.x * IEF_T * IEF_D;
+    if (ob) ob += (size_t)c.enc_row * IEF_D;
     const bool fix = flags && flags[2 * c.video + m] != 0;
     const float big = RaggedLimits<T>::max();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < IEF_T; r += 4) {
+    const int nr = nrows ? nrows : ragged_rows(c.valid);
+    // four rows of the wave per trip: all their loads are issued before the first store (a 40-row chunk is 2-3 trips of pure latency)
+    for (int r0 = wave; r0 < nr; r0 += 16) {
+        f32x4 v[4][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int col = 4 * lane + 256 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < c.valid) {
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)src[(size_t)r * IEF_D + col + e];
-                if (fix) {
+            for (int j = 0; j < 3; ++j) {
+                const int col = 4 * lane + 256 * j;
+                v[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < c.valid) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = v[e];
-                        v[e] = (x != x) ? 0.f : (x > big ? big : (x < -big ? -big : x));     // torch.nan_to_num(nan=0.0)
-                    }
+                    for (int e = 0; e < 4; ++e) v[u][j][e] = (float)src[(size_t)r * IEF_D + col + e];
                 }
             }
-            *(f32x4*)(out + (size_t)r * IEF_D + col) = v;
-            if (ob) *(bf16x4_t*)(ob + (size_t)r * IEF_D + col) = to_bf16x4(v);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u;
+            if (r >= nr) break;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = 4 * lane + 256 * j;
+                f32x4 w = v[u][j];
+                if (fix && r < c.valid) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = w[e];
+                        w[e] = (x != x) ? 0.f : (x > big ? big : (x < -big ? -big : x));     // torch.nan_to_num(nan=0.0)
+                    }
+                }
+                *(f32x4*)(out + (size_t)r * IEF_D + col) = w;
+                if (ob) *(bf16x4_t*)(ob + (size_t)r * IEF_D + col) = to_bf16x4(w);
+            }
         }
     }
 }
@@ -98,7 +123,7 @@ __global__ __launch_bounds__(256) void iefvad_compact_rows_kernel(CompactArgs a)
     const int m = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = wave; r < c.valid; r += 4) {
-        const size_t s = ((size_t)blockIdx.x * IEF_T + r) * IEF_D + 4 * lane, d = ((size_t)c.src_row + r) * IEF_D + 4 * lane;
+        const size_t s = ((size_t)c.enc_row + r) * IEF_D + 4 * lane, d = ((size_t)c.src_row + r) * IEF_D + 4 * lane;
         if (a.x[m]) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) *(f32x4*)(a.xc[m] + d + 256 * j) = *(const f32x4*)(a.x[m] + s + 256 * j);
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(256) void iefvad_rows_out_kernel(const float* s0, c
     const RaggedChunk c = chunks[blockIdx.x];
     const int r = threadIdx.x;
     if (r < c.valid) {
-        const size_t s = (size_t)blockIdx.x * IEF_T + r, d = (size_t)c.src_row + r;
+        const size_t s = (size_t)c.enc_row + r, d = (size_t)c.src_row + r;
         if (d0) d0[d] = s0[s];
         if (d1) d1[d] = s1[s];
         if (d2) d2[d] = s2[s];

@@ -346,8 +346,8 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
 
     `ragged` (default: whenever the model has `forward_videos`, i.e. `iefvad_amd.MMFMIL` on a HIP device, and batch_chunks > 0):
     the packed batches go through `MMFMIL.forward_videos` -- only the VALID rows of every video are staged and uploaded, the
-    chunker, the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing run on the device, and everything behind the
-    encoder runs on the valid rows only (csrc/ragged.h).  Same scores (bit for bit in the f32 and bf16 modes).
+    chunker, the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing run on the device, and no stage computes the
+    padding (one pad row per chunk stands for all of them, csrc/ragged.h).  Same scores (bit for bit in the f32 and bf16 modes).
 
     lanes > 1 (HIP devices, `iefvad_amd.MMFMIL`): consecutive forwards go round-robin to `lanes` HIP streams, each with a
     lane of the model (`MMFMIL.lanes`: same parameters, own library handle and workspace) and its own pinned staging.

@@ -168,9 +168,13 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
  *                       (NaN -> 0, +-inf -> the largest / smallest finite value of `in_dtype`); zero: rows are used as they are
  *   logits, w_i_mean, w_e_mean   device, [sum(lengths)] fp32 each, the means nullable: per-snippet results in the same order
  * Chunks are laid out on the device (zero padded; the all-zero chunk that process_split appends to a len % 256 == 0 video,
- * whose rows test.py:121 slices away, is not built), the encoder runs on whole chunks (attention is unmasked over the padded
- * window, as in the reference), and everything behind the encoder -- row-wise in the reference, imf_vad.py:125-150 -- runs on
- * the valid rows only.  Results equal those of iefvad_forward on the host-padded chunks (bit for bit in the F32 and BF16 modes).
+ * whose rows test.py:121 slices away, is not built).  Attention is unmasked over the padded window, as in the reference,
+ * but the pad rows of a window are identical in every layer: the row set holds ONE of them per chunk, the row-wise stages
+ * (projections, LayerNorms and everything behind the encoder, imf_vad.py:125-150) run on valid + 1 rows per chunk, and the
+ * attention kernels read row min(r, valid) for row r of the window -- every product and sum of the padded computation.
+ * Results equal those of iefvad_forward on the host-padded chunks (bit for bit in the F32 and BF16 modes).  FP16X3 (one
+ * operand scale per whole chunk) and IEFVAD_DENSE_ENCODER=1 (environment, read at iefvad_create) keep whole chunks in the
+ * encoder and gather the valid rows behind it.
  * Workspace: iefvad_videos_workspace_bytes.  Enqueued on `stream`; `lengths` is consumed before the call returns. */
 size_t iefvad_videos_workspace_bytes(const iefvad_handle* h, const int32_t* lengths, int32_t nvideos);
 int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev_rows, int32_t in_dtype,

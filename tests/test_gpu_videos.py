@@ -1,6 +1,7 @@
 """`iefvad_forward_videos` (include/iefvad.h, csrc/ragged.h): whole videos cross the boundary as their VALID rows; the
 chunker (tools.py:100-114), the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing (test.py:119-121,131-138)
-run on the device and everything behind the encoder runs on the valid rows only.  Checked against the reference-shaped
+run on the device; the encoder keeps ONE pad row per chunk (all pad rows of a window are identical in every layer, the
+attention kernels read row min(r, valid)) and everything behind it runs on that row set.  Checked against the reference-shaped
 route: host-side process_split + `_unpack_item` + the dense forward on zero-padded chunks, which the capture tests pin to the
 reference's own test()."""
 import argparse
@@ -72,6 +73,22 @@ def test_forward_videos_is_bit_identical_to_the_padded_forward(compute, micro_ba
             assert float((got[k] - want[k]).abs().max()) <= 1e-6, k
         else:
             assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_whole_chunk_encoder_switch_gives_the_same_bits(compute, monkeypatch):
+    """IEFVAD_DENSE_ENCODER=1 (read at model creation) keeps whole 256-row chunks in the encoder and gathers the valid rows
+    behind it -- round 3's first design, kept for the A/B: same scores, bit for bit."""
+    vids = videos(EDGE_LENGTHS, seed=12)
+    model, _ = make_model(compute, outputs="scores")
+    got = ragged(model, vids)
+    del model
+    monkeypatch.setenv("IEFVAD_DENSE_ENCODER", "1")
+    model, _ = make_model(compute, outputs="scores")
+    monkeypatch.delenv("IEFVAD_DENSE_ENCODER")
+    want = ragged(model, vids)
+    assert torch.equal(got["logits"], want["logits"])
+    assert float((got["w_i_mean"] - want["w_i_mean"]).abs().max()) <= (1e-6 if compute == "bf16" else 0.0)
 
 
 def test_forward_videos_large_batch_bf16_kernels_and_bf16x6_tolerance():
