@@ -27,6 +27,7 @@
 #include "outproj_ln_bf16.h"
 #include "refine_chain_bf16.h"
 #include "outproj_ln_chain_bf16.h"
+#include "inproj_chain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
 
@@ -60,6 +61,8 @@ struct iefvad_handle {
     bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
     bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
     bool ol_v1;            // IEFVAD_OL_V1=1: bf16 mode's fused out_proj + LayerNorm on the first design (outproj_ln_bf16.h) instead of the chain-style one
+    char* iproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: in_proj weights in per-wave fragment order, q | k | v passes (inproj_chain_bf16.h)
+    bool no_inproj_chain;  // IEFVAD_NO_INPROJ_CHAIN=1: bf16 mode's in_proj on the 256 x 256 ring kernel (and the stand-alone cast in front of it)
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
     bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
     bool no_chain;         // IEFVAD_NO_CHAIN=1: bf16 mode runs the refinement as 2K projection launches + the scorer kernel
@@ -162,6 +165,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     { const char* v = getenv("IEFVAD_NO_CHAIN"); h->no_chain = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_OL_V1"); h->ol_v1 = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_DENSE_ENCODER"); h->dense_encoder = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_NO_INPROJ_CHAIN"); h->no_inproj_chain = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -194,6 +198,15 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_split_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ATS_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_inproj_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                IC_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_inproj_chain_f32in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                IC_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
     if (e == hipSuccess)
@@ -218,8 +231,10 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena_b) (void)hipFree(h->arena_b);
     if (h->chain_stream) (void)hipFree(h->chain_stream);
     for (int m = 0; m < 2; ++m)
-        for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l)
+        for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) {
             if (h->oproj_stream[m][l]) (void)hipFree(h->oproj_stream[m][l]);
+            if (h->iproj_stream[m][l]) (void)hipFree(h->iproj_stream[m][l]);
+        }
     if (h->arena_s) (void)hipFree(h->arena_s);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
@@ -337,7 +352,10 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
         for (int m = 0; m < 2; ++m)
             for (int l = 0; l < L; ++l) {
                 if (!h->oproj_stream[m][l]) HIP_TRY(hipMalloc((void**)&h->oproj_stream[m][l], wstream_bytes()));
-                hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(256), dim3(256), 0, stream, h->out_wb[m][l], h->oproj_stream[m][l]);
+                hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(256), dim3(256), 0, stream, h->out_wb[m][l], h->oproj_stream[m][l], 1);
+                HIP_TRY(hipGetLastError());
+                if (!h->iproj_stream[m][l]) HIP_TRY(hipMalloc((void**)&h->iproj_stream[m][l], wstream_bytes(IC_NPASS)));
+                hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(512), dim3(256), 0, stream, h->in_wb[m][l], h->iproj_stream[m][l], IC_NPASS);
                 HIP_TRY(hipGetLastError());
             }
         if (K > 0) {
@@ -703,7 +721,10 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             wem_out = rg->w_e_mean ? lg_scratch + 2 * R : nullptr;
         }
 
-        // 0. inputs: `.to(torch.float)` (imf_vad.py:41-42); bf16 mode also needs the bf16 operand copy
+        // bf16 mode, full grids: in_proj on the row-block kernel (inproj_chain_bf16.h); its first layer reads the fp32 rows
+        const bool ip_chain = bf && !h->no_inproj_chain && rows % IC_BM == 0 && (rows / IC_BM) * 2 >= 256;
+        // 0. inputs: `.to(torch.float)` (imf_vad.py:41-42); bf16 mode also needs the bf16 operand copy (unless ip_chain)
+        const bool need_xb0 = bf && !ip_chain;
         const float* cur[2];
         const char* pi = (const char*)pi_;
         const char* pe = (const char*)pe_;
@@ -713,7 +734,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 const size_t o = (size_t)rg->enc_used_rows * D, n = (size_t)(rows - rg->enc_used_rows) * D;
                 for (int m = 0; m < 2; ++m) {
                     HIP_TRY(hipMemsetAsync(xin[m] + o, 0, n * sizeof(float), stream));
-                    if (bf) HIP_TRY(hipMemsetAsync(xb[m] + o, 0, n * sizeof(bf16_t), stream));
+                    if (need_xb0) HIP_TRY(hipMemsetAsync(xb[m] + o, 0, n * sizeof(bf16_t), stream));
                 }
             }
             hipEvent_t e = tm.begin(ST_CAST);
@@ -723,8 +744,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             hipLaunchKernelGGL(iefvad_nanflag_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,          \
                                (const T*)rg->ev_rows, rg->d_chunks, (int*)rg->d_flags);                                     \
         hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,         \
-                           (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], bf ? xb[0] : (bf16_t*)nullptr,  \
-                           bf ? xb[1] : (bf16_t*)nullptr, enc_rows_mode ? 0 : IEF_T);                                       \
+                           (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], need_xb0 ? xb[0] : (bf16_t*)nullptr, \
+                           need_xb0 ? xb[1] : (bf16_t*)nullptr, enc_rows_mode ? 0 : IEF_T);                                  \
     } while (0)
             if (in_dtype == IEFVAD_IN_F32) RAGGED_IN(float);
             else if (in_dtype == IEFVAD_IN_F16) RAGGED_IN(__half);
@@ -737,7 +758,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         } else if (in_dtype == IEFVAD_IN_F32) {
             cur[0] = (const float*)pi;
             cur[1] = (const float*)pe;
-            if (bf) {
+            if (need_xb0) {
                 hipEvent_t e = tm.begin(ST_CAST);
                 int rc = launch_cast<float>(pi, pe, nullptr, nullptr, xb[0], xb[1], R * D, 2, stream);
                 tm.end(e);
@@ -745,8 +766,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             }
         } else {
             hipEvent_t e = tm.begin(ST_CAST);
-            bf16_t* b0p = bf ? xb[0] : nullptr;
-            bf16_t* b1p = bf ? xb[1] : nullptr;
+            bf16_t* b0p = need_xb0 ? xb[0] : nullptr;
+            bf16_t* b1p = need_xb0 ? xb[1] : nullptr;
             int rc = (in_dtype == IEFVAD_IN_F16) ? launch_cast<__half>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, 2, stream)
                                                  : launch_cast<__hip_bfloat16>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, 2, stream);
             tm.end(e);
@@ -780,6 +801,21 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         // 1. temporal encoder (imf_vad.py:113-123): L x { in_proj, attention, out_proj + residual, LayerNorm }
         for (int l = 0; l < L; ++l) {
             Proj p;
+            if (ip_chain) {
+                InProjChainArgs ia;
+                memset(&ia, 0, sizeof(ia));
+                for (int m = 0; m < 2; ++m) {
+                    ia.p[m].A = (l == 0) ? (const void*)cur[m] : (const void*)xb[m];
+                    ia.p[m].stream = h->iproj_stream[m][l]; ia.p[m].bias = h->in_b[m][l]; ia.p[m].C = qkvb[m];
+                }
+                ia.M = rows; ia.alpha = qscale * 1.4426950408889634f; ia.wave_stride = (unsigned)wstream_wave_stride_bytes(IC_NPASS);
+                hipEvent_t e = tm.begin(ST_QKV);
+                if (l == 0) hipLaunchKernelGGL(iefvad_inproj_chain_f32in_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
+                else hipLaunchKernelGGL(iefvad_inproj_chain_bf16_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
+                tm.end(e);
+                tm.gemm_launches += 1;
+                HIP_TRY(hipGetLastError());
+            }
             memset(&p, 0, sizeof(p));
             p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
             // q is pre-scaled for the softmax by log2(e)/sqrt(96): both attention kernels use exp2
@@ -791,7 +827,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 p.bias[m] = h->in_b[m][l];
                 if (bf) p.Cb[m] = qkvb[m]; else p.C[m] = qkv[m];
             }
-            if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
+            if (!ip_chain)
+                if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
 
             hipEvent_t e = tm.begin(ST_ATT);
             if (bf) {

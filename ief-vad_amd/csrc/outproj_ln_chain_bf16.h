@@ -29,12 +29,13 @@
 #define OC_PIECES (OC_KT * OC_NB)                    // 144 per wave
 #define OC_PAD_PIECES OC_DEPTH
 
-static inline size_t wstream_wave_stride_bytes() { return (size_t)(OC_PIECES + OC_PAD_PIECES) * 1024; }
-static inline size_t wstream_bytes() { return 8 * wstream_wave_stride_bytes(); }
+// npass = 1: a [768, 768] matrix (out_proj); npass = 3: the packed [2304, 768] in_proj matrix, pass = q | k | v (inproj_chain_bf16.h)
+static inline size_t wstream_wave_stride_bytes(int npass = 1) { return (size_t)(npass * OC_PIECES + OC_PAD_PIECES) * 1024; }
+static inline size_t wstream_bytes(int npass = 1) { return 8 * wstream_wave_stride_bytes(npass); }
 
-// W [768, 768] bf16 -> per wave w: pieces (kt, b), lane (r, q): 8 bf16 = W[96 w + 16 b + r][32 kt + 8 q .. + 7]
-__global__ __launch_bounds__(256) void iefvad_wstream_pack_kernel(const bf16_t* W, char* stream) {
-    const size_t per_wave = (size_t)(OC_PIECES + OC_PAD_PIECES) * 64;
+// W [768 npass, 768] bf16 -> per wave w: pieces (pass, kt, b), lane (r, q): 8 bf16 = W[768 pass + 96 w + 16 b + r][32 kt + 8 q .. + 7]
+__global__ __launch_bounds__(256) void iefvad_wstream_pack_kernel(const bf16_t* W, char* stream, int npass) {
+    const size_t per_wave = (size_t)(npass * OC_PIECES + OC_PAD_PIECES) * 64;
     const size_t total = 8 * per_wave;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
         const int w = (int)(u / per_wave);
@@ -42,9 +43,10 @@ __global__ __launch_bounds__(256) void iefvad_wstream_pack_kernel(const bf16_t* 
         const int lane = (int)(v & 63);
         const int piece = (int)(v >> 6);
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (piece < OC_PIECES) {
-            const int kt = piece / OC_NB, b = piece % OC_NB, r = lane & 15, q = lane >> 4;
-            val = *(const f32x4*)(W + (size_t)(96 * w + 16 * b + r) * IEF_D + 32 * kt + 8 * q);
+        if (piece < npass * OC_PIECES) {
+            const int pass = piece / OC_PIECES, pp = piece % OC_PIECES;
+            const int kt = pp / OC_NB, b = pp % OC_NB, r = lane & 15, q = lane >> 4;
+            val = *(const f32x4*)(W + (size_t)(IEF_D * pass + 96 * w + 16 * b + r) * IEF_D + 32 * kt + 8 * q);
         }
         *(f32x4*)(stream + u * 16) = val;
     }

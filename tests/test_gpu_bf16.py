@@ -167,6 +167,33 @@ def test_refinement_chain_kernel_equals_the_2k_launch_path(monkeypatch, K, lam, 
         assert torch.equal(chain[k], plain[k]), (k, (chain[k].float() - plain[k].float()).abs().max().item())
 
 
+@pytest.mark.parametrize("L,in_dtype,B", [(2, np.float32, 64), (3, np.float16, 64), (2, np.float32, 96)])
+def test_inproj_row_block_kernel_equals_the_ring_kernel(monkeypatch, L, in_dtype, B):
+    """bf16 mode, >= 64 chunks: in_proj runs on the row-block kernel (csrc/inproj_chain_bf16.h): a workgroup keeps 64 rows as
+    one LDS image, every wave streams its own 96 columns of q, k and v; the first layer reads the fp32 rows and rounds them to
+    bf16 itself (no cast kernel, no bf16 copy of the inputs).  Same products in the same k order, the ring kernel's epilogue:
+    every output must equal the ring-kernel path (IEFVAD_NO_INPROJ_CHAIN=1 at model creation) bit for bit.  NaN / inf rows
+    included; fp16 inputs take the widening cast first; B = 96 with micro_batch = 64 runs a second, smaller pass (32 chunks:
+    the ring kernel) through the same handle."""
+    sd = synth.make_state_dict(13, 768, L, 3)
+    img, ev = synth.make_inputs(36, B)
+    img[2, 100, 9] = np.nan
+    ev[5, 0, 0] = np.inf
+    ti, te = torch.from_numpy(img.astype(in_dtype)).cuda(), torch.from_numpy(ev.astype(in_dtype)).cuda()
+    kw = dict(outputs="full", micro_batch=64)
+    with torch.no_grad():
+        rowblock = make_model(L, 3, 0.5, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_NO_INPROJ_CHAIN", "1")
+        ring = make_model(L, 3, 0.5, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+    assert set(rowblock) == set(ring)
+    for k in rowblock:
+        a, b = rowblock[k].float(), ring[k].float()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), k
+        assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (k, (a - b).abs().max().item())
+    bad = (~torch.isfinite(rowblock["logits"])).reshape(B, 256).any(dim=1).cpu().numpy()
+    assert bad[2] and bad[5] and bad.sum() == 2
+
+
 def test_refinement_chain_kernel_propagates_non_finite_rows(monkeypatch):
     """A NaN / inf in one snippet's fused state must stay in that row through the chain kernel exactly as through the
     projection launches (rows are independent in imf_vad.py:146-150)."""
