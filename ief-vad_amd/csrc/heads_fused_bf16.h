@@ -217,13 +217,13 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_fused_bf16_kernel(HeadsFu
 }
 
 // row means of the normalised weights from the fused kernel's partial sums: fixed order, one thread per row
-__global__ __launch_bounds__(256) void iefvad_rowmean_finish_kernel(const float* part, float* n_i_mean, float* n_e_mean, int nrows) {
+// (np partials per row and modality: HF_NBLK here, HC_NPART from heads_chain_bf16.h)
+__global__ __launch_bounds__(256) void iefvad_rowmean_finish_kernel(const float* part, float* n_i_mean, float* n_e_mean, int nrows, int np) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= nrows) return;
-    const float* p = part + (size_t)row * 2 * HF_NBLK;
+    const float* p = part + (size_t)row * 2 * np;
     float si = 0.f, se = 0.f;
-#pragma unroll
-    for (int b = 0; b < HF_NBLK; ++b) { si += p[b]; se += p[HF_NBLK + b]; }
+    for (int b = 0; b < np; ++b) { si += p[b]; se += p[np + b]; }
     if (n_i_mean) n_i_mean[row] = si * (1.0f / IEF_D);
     if (n_e_mean) n_e_mean[row] = se * (1.0f / IEF_D);
 }

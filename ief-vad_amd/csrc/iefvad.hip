@@ -28,6 +28,7 @@
 #include "refine_chain_bf16.h"
 #include "outproj_ln_chain_bf16.h"
 #include "inproj_chain_bf16.h"
+#include "heads_chain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
 
@@ -62,6 +63,8 @@ struct iefvad_handle {
     bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
     bool ol_v1;            // IEFVAD_OL_V1=1: bf16 mode's fused out_proj + LayerNorm on the first design (outproj_ln_bf16.h) instead of the chain-style one
     char* iproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: in_proj weights in per-wave fragment order, q | k | v passes (inproj_chain_bf16.h)
+    char* heads_stream;    // bf16 mode: the four head matrices in per-wave fragment order (heads_chain_bf16.h)
+    bool heads_v1;         // IEFVAD_HEADS_V1=1: bf16 mode's fused heads + fusion on the 256 x 64 ring kernel (heads_fused_bf16.h)
     bool no_inproj_chain;  // IEFVAD_NO_INPROJ_CHAIN=1: bf16 mode's in_proj on the 256 x 256 ring kernel (and the stand-alone cast in front of it)
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
     bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
@@ -166,6 +169,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     { const char* v = getenv("IEFVAD_OL_V1"); h->ol_v1 = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_DENSE_ENCODER"); h->dense_encoder = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_INPROJ_CHAIN"); h->no_inproj_chain = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_HEADS_V1"); h->heads_v1 = v && v[0] == '1'; }
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -201,6 +205,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_heads_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HC_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_inproj_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 IC_LDS_BYTES);
     if (e == hipSuccess)
@@ -230,6 +237,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->arena_b) (void)hipFree(h->arena_b);
     if (h->chain_stream) (void)hipFree(h->chain_stream);
+    if (h->heads_stream) (void)hipFree(h->heads_stream);
     for (int m = 0; m < 2; ++m)
         for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) {
             if (h->oproj_stream[m][l]) (void)hipFree(h->oproj_stream[m][l]);
@@ -358,6 +366,9 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
                 hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(512), dim3(256), 0, stream, h->in_wb[m][l], h->iproj_stream[m][l], IC_NPASS);
                 HIP_TRY(hipGetLastError());
             }
+        if (!h->heads_stream) HIP_TRY(hipMalloc((void**)&h->heads_stream, heads_stream_bytes()));
+        hipLaunchKernelGGL(iefvad_heads_pack_kernel, dim3(512), dim3(256), 0, stream, h->head_wb[0], h->head_wb[1], h->heads_stream);
+        HIP_TRY(hipGetLastError());
         if (K > 0) {
             // the same bf16 matrices (and the fp32 biases) once more, in the chain kernel's per-wave piece order
             if (!h->chain_stream) HIP_TRY(hipMalloc((void**)&h->chain_stream, chain_stream_bytes(K)));
@@ -809,6 +820,9 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                     ia.p[m].stream = h->iproj_stream[m][l]; ia.p[m].bias = h->in_b[m][l]; ia.p[m].C = qkvb[m];
                 }
                 ia.M = rows; ia.alpha = qscale * 1.4426950408889634f; ia.wave_stride = (unsigned)wstream_wave_stride_bytes(IC_NPASS);
+#ifdef IC_DIAG
+                { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_IC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ia.diag = dg; }
+#endif
                 hipEvent_t e = tm.begin(ST_QKV);
                 if (l == 0) hipLaunchKernelGGL(iefvad_inproj_chain_f32in_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
                 else hipLaunchKernelGGL(iefvad_inproj_chain_bf16_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
@@ -978,7 +992,40 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= 256;
         // 4 + 5 in one kernel (bf16 mode, full grids): the K refinement steps and the scorer with the state on chip, refine_chain_bf16.h
         const bool chain = bf && K > 0 && !h->no_chain && h->chain_stream && rows % RC_BM == 0 && rows / RC_BM >= 256;
-        if (heads_fused) {
+        // second design: 64-row blocks on the row-block structure (heads_chain_bf16.h); same bits except the order of the row sums
+        const bool heads_rows = heads_fused && !h->heads_v1 && h->heads_stream && rows % HC_BM == 0 && (rows / HC_BM) * HC_THIRDS >= 256;
+        if (heads_rows) {
+            HeadsChainArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            for (int m = 0; m < 2; ++m) { ha.A[m] = xtb[m]; ha.bias[m] = h->head_b[m]; }
+            ha.stream = h->heads_stream;
+            ha.mu[0] = out->image_mu ? mu_i : nullptr;
+            ha.lv[0] = out->image_logvar ? lv_i : nullptr;
+            ha.mu[1] = out->event_mu ? mu_e : nullptr;
+            ha.lv[1] = out->event_logvar ? lv_e : nullptr;
+            ha.n[0] = out->w_i ? out->w_i + row0 * D : nullptr;
+            ha.n[1] = out->w_e ? out->w_e + row0 * D : nullptr;
+            ha.z = z;
+            ha.zb = chain ? nullptr : zb;
+            const bool means = wim_out || wem_out;
+            ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 48 of its 768 floats per row
+            ha.M = rows; ha.factor = factor; ha.eps = c.epsilon; ha.wave_stride = (unsigned)heads_stream_wave_stride_bytes();
+#ifdef HC_DIAG
+            { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_HC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ha.diag = dg; }
+#endif
+            hipEvent_t e = tm.begin(ST_HEAD);
+            hipLaunchKernelGGL(iefvad_heads_chain_bf16_kernel, dim3(rows / HC_BM, HC_THIRDS), dim3(512), HC_LDS_BYTES, stream, ha);
+            tm.end(e);
+            tm.gemm_launches += 1;
+            HIP_TRY(hipGetLastError());
+            if (means) {
+                e = tm.begin(ST_FUSION);
+                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
+                                   wim_out, wem_out, rows, HC_NPART);
+                tm.end(e);
+                HIP_TRY(hipGetLastError());
+            }
+        } else if (heads_fused) {
             HeadsFusedArgs ha;
             memset(&ha, 0, sizeof(ha));
             for (int m = 0; m < 2; ++m) { ha.A[m] = xtb[m]; ha.W[m] = h->head_wb[m]; ha.bias[m] = h->head_b[m]; }
@@ -1001,7 +1048,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             if (means) {
                 e = tm.begin(ST_FUSION);
                 hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
-                                   wim_out, wem_out, rows);
+                                   wim_out, wem_out, rows, HF_NBLK);
                 tm.end(e);
                 HIP_TRY(hipGetLastError());
             }

@@ -33,7 +33,13 @@ struct InProjChainArgs {
     int M;                   // multiple of 64
     float alpha;             // scale of the q columns
     unsigned wave_stride;
+    unsigned long long* diag; // IC_DIAG builds only: 8 s_memtime stamps per workgroup (tools/rowblock_diag.py)
 };
+#ifdef IC_DIAG
+#define IC_STAMP(i) do { if (args.diag && t == 0) args.diag[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IC_STAMP(i)
+#endif
 
 template <bool A32>
 __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, char* lds) {
@@ -43,6 +49,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * IC_BM;
+    IC_STAMP(0);
 
     // ---- the image: 64 rows x 96 chunks of 16 bytes (8 bf16), chunk c of row r at r * 1536 + ((c & ~15) | ((c ^ r) & 15)) * 16
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(P.stream + (size_t)wave * args.wave_stride), 0, (int)args.wave_stride, 0x00020000);
@@ -89,6 +96,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
     for (int j = 0; j < 4; ++j) rd[j] = m * (IEF_D * 2) + (((4 * j + q) ^ m) & 15) * 16;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     GB2_BARRIER();
+    IC_STAMP(1);
 
     bf16_t* stage = (bf16_t*)(lds + OC_IMG_BYTES + wave * IC_STAGE_BYTES);
     int p = 0;
@@ -126,6 +134,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
                 }
             }
         }
+        IC_STAMP(2 + 2 * pass);
         // ---- epilogue of the pass: (acc + bias) * scale -> bf16, 16 rows at a time through the wave's private tile.
         // accumulator tile (a, b): lane (m, q) holds row 16 a + m, columns 16 b + 4 q .. + 3
         const float sc = pass == 0 ? args.alpha : 1.f;
@@ -146,6 +155,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
                 GB2_STORE((bf16x8*)(cbase + (size_t)(16 * a + row) * (3 * IEF_D) + 8 * ch), w);
             }
         }
+        IC_STAMP(3 + 2 * pass);
     }
 #undef IC_LOAD
 #pragma unroll

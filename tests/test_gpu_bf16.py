@@ -167,6 +167,37 @@ def test_refinement_chain_kernel_equals_the_2k_launch_path(monkeypatch, K, lam, 
         assert torch.equal(chain[k], plain[k]), (k, (chain[k].float() - plain[k].float()).abs().max().item())
 
 
+@pytest.mark.parametrize("outputs,overflow,B", [("full", False, 64), ("scores", False, 40), ("full", True, 64)])
+def test_heads_row_block_kernel_equals_the_ring_kernel(monkeypatch, outputs, overflow, B):
+    """bf16 mode, >= 22 chunks: heads + fusion run on the row-block kernel (csrc/heads_chain_bf16.h): 64 rows resident as an
+    LDS image (x_i, then x_e), a wave streams the four head matrices of its 32 columns and fuses in registers.  Same products
+    in the same k order and the same fusion code as the 256 x 64 ring kernel (csrc/heads_fused_bf16.h, IEFVAD_HEADS_V1=1 at
+    model creation): every output bit for bit, the row means of the weights to fp32 rounding (24 partial sums instead of 12).
+    `overflow`: the literal formula's inf / inf = NaN column (imf_vad.py:135-142) must come out the same."""
+    K = 0 if overflow else 3
+    sd = synth.make_state_dict(14, 768, 2, K)
+    if overflow:
+        for k in ("temporal.image_logvar.bias", "temporal.event_logvar.bias"):
+            sd[k] = sd[k].clone()
+            sd[k][5] = -95.0
+    img, ev = synth.make_inputs(37, B)
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    with torch.no_grad():
+        rows = make_model(2, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_HEADS_V1", "1")
+        ring = make_model(2, K, 0.5, "StudentT", 8, sd, outputs=outputs)(ti, te, None, None, None)
+    assert set(rows) == set(ring)
+    for k in rows:
+        a, b = rows[k].float(), ring[k].float()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), k
+        if k in ("w_i_mean", "w_e_mean"):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6, equal_nan=True), k
+        else:
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (k, (a - b).abs().max().item())
+    if overflow:
+        assert torch.isnan(rows["fused"][..., 5]).all() and torch.isfinite(rows["fused"][..., :5]).all()
+
+
 @pytest.mark.parametrize("L,in_dtype,B", [(2, np.float32, 64), (3, np.float16, 64), (2, np.float32, 96)])
 def test_inproj_row_block_kernel_equals_the_ring_kernel(monkeypatch, L, in_dtype, B):
     """bf16 mode, >= 64 chunks: in_proj runs on the row-block kernel (csrc/inproj_chain_bf16.h): a workgroup keeps 64 rows as
