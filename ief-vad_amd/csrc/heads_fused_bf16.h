@@ -217,13 +217,19 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_fused_bf16_kernel(HeadsFu
 }
 
 // row means of the normalised weights from the fused kernel's partial sums: fixed order, one thread per row
-// (np partials per row and modality: HF_NBLK here, HC_NPART from heads_chain_bf16.h)
+// (np partials per row and modality: HF_NBLK here, HC_NPART from heads_chain_bf16.h; a multiple of 4).  One thread per (row, modality):
+// its np floats are contiguous, neighbouring threads read neighbouring 16-byte vectors.
 __global__ __launch_bounds__(256) void iefvad_rowmean_finish_kernel(const float* part, float* n_i_mean, float* n_e_mean, int nrows, int np) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int row = id >> 1, mod = id & 1;
     if (row >= nrows) return;
-    const float* p = part + (size_t)row * 2 * np;
-    float si = 0.f, se = 0.f;
-    for (int b = 0; b < np; ++b) { si += p[b]; se += p[np + b]; }
-    if (n_i_mean) n_i_mean[row] = si * (1.0f / IEF_D);
-    if (n_e_mean) n_e_mean[row] = se * (1.0f / IEF_D);
+    float* dst = mod ? n_e_mean : n_i_mean;
+    if (!dst) return;
+    const float* p = part + ((size_t)row * 2 + mod) * np;
+    float s = 0.f;
+    for (int b = 0; b < np; b += 4) {
+        const f32x4 v = *(const f32x4*)(p + b);
+        s += v[0]; s += v[1]; s += v[2]; s += v[3];
+    }
+    dst[row] = s * (1.0f / IEF_D);
 }

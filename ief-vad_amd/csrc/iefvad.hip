@@ -1020,7 +1020,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             HIP_TRY(hipGetLastError());
             if (means) {
                 e = tm.begin(ST_FUSION);
-                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
+                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
                                    wim_out, wem_out, rows, HC_NPART);
                 tm.end(e);
                 HIP_TRY(hipGetLastError());
@@ -1047,7 +1047,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             HIP_TRY(hipGetLastError());
             if (means) {
                 e = tm.begin(ST_FUSION);
-                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
+                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
                                    wim_out, wem_out, rows, HF_NBLK);
                 tm.end(e);
                 HIP_TRY(hipGetLastError());

@@ -7,7 +7,7 @@
 //   * every wave streams ITS OWN 96 columns of q, then of k, then of v (three passes over k, 96 accumulators) as 1 KB pieces
 //     in fragment order (iefvad_wstream_pack_kernel), six in flight in registers; the stream runs on across the passes, so
 //     a pass's epilogue overlaps the next pass's first pieces; no barrier after the image is in place;
-//   * a pass's epilogue goes through a wave-private 3 KB LDS tile (16 rows x 96 columns bf16): bias, q scale, bf16, 16-byte
+//   * a pass's epilogue goes through wave-private 3 KB LDS tiles (16 rows x 96 columns bf16, two per wave): bias, q scale, bf16, 16-byte
 //     non-temporal stores of 192-byte row segments.
 // The 256 x 256 ring kernel (gemm_bf16.h) re-reads a 96 KB A panel nine times through L2 for 256 rows and stops at every
 // k-tile barrier; here the weights move (3.5 MB per block, the measured 110-120 GB/s per CU) and the rows stay.
@@ -20,7 +20,7 @@
 #define IC_NPASS 3
 #define IC_STAGE_LD 104                                   // bf16 per staged row (208 B)
 #define IC_STAGE_BYTES (16 * IC_STAGE_LD * 2)             // 3,328 B per wave
-#define IC_LDS_BYTES (OC_IMG_BYTES + 8 * IC_STAGE_BYTES)  // 124,928 B
+#define IC_LDS_BYTES (OC_IMG_BYTES + 16 * IC_STAGE_BYTES) // 151,552 B: two staging tiles per wave
 
 struct InProjChainProblem {
     const void* A;           // [M, 768] rows: fp32 (A32) or bf16
@@ -98,7 +98,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
     GB2_BARRIER();
     IC_STAMP(1);
 
-    bf16_t* stage = (bf16_t*)(lds + OC_IMG_BYTES + wave * IC_STAGE_BYTES);
+    bf16_t* stage0 = (bf16_t*)(lds + OC_IMG_BYTES + wave * (2 * IC_STAGE_BYTES));      // two tiles: row tile a + 1 is written while a's rows are read back
     int p = 0;
 #pragma unroll 1
     for (int pass = 0; pass < IC_NPASS; ++pass) {
@@ -141,6 +141,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
         bf16_t* cbase = P.C + (size_t)m0 * (3 * IEF_D) + IEF_D * pass + 96 * wave;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
+            bf16_t* stage = stage0 + (a & 1) * (IC_STAGE_BYTES / 2);
 #pragma unroll
             for (int b = 0; b < OC_NB; ++b) {
                 f32x4 v = acc[a][b] + bv[b];
