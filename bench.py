@@ -57,9 +57,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROAR
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
 PROFILE_ROUND = "r03"                                           # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
-               "bf16": "iefvad_gemm_bf16_w256_kernel (in_proj) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + "
-                       "scorer, one launch) + iefvad_heads_fused_bf16_kernel (heads + fusion) + iefvad_outproj_ln_chain_bf16_kernel "
-                       "(out_proj + LayerNorm)",
+               "bf16": "iefvad_inproj_chain_f32in_kernel / iefvad_inproj_chain_bf16_kernel (in_proj; the first layer rounds the fp32 "
+                       "rows to bf16 itself) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + scorer, one launch) + "
+                       "iefvad_heads_chain_bf16_kernel (heads + fusion) + iefvad_outproj_ln_chain_bf16_kernel (out_proj + LayerNorm)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -172,8 +172,9 @@ def roofline_block(compute, stage, steps, rows_per_step):
         pure_flops = (4 * (2 * D * 3 * D) + K_STEPS * 2 * (2 * D * D)) * rows_per_step      # in_proj + refinement launches only
         pure_ms = (stage["qkv_gemm_ms"] + stage["refine_gemm_ms"]) / steps
         r["achieved_pure_projection_launches"] = pure_flops / (pure_ms * 1e-3) / 1e12
-        r["note"] = ("the 25 projections of a pass run as 6 launches: 2 x in_proj, 2 x iefvad_outproj_ln_chain_bf16_kernel (out_proj + "
-                     "residual + LayerNorm), iefvad_heads_fused_bf16_kernel (both modalities' heads AND the precision-weighted "
+        r["note"] = ("the 25 projections of a pass run as 6 launches of row-block kernels (a workgroup keeps 64 rows in LDS and every "
+                     "wave streams its own weight columns): 2 x in_proj, 2 x iefvad_outproj_ln_chain_bf16_kernel (out_proj + "
+                     "residual + LayerNorm), iefvad_heads_chain_bf16_kernel (both modalities' heads AND the precision-weighted "
                      "fusion) and ONE iefvad_refine_chain_bf16_kernel (the 2K refinement projections and the scorer, state on "
                      "chip); the fused launches are counted whole as GEMM time and the stand-alone LayerNorm / fusion / scorer "
                      "kernels do not run.  achieved_pure_projection_launches = the same quantity over the in_proj and "

@@ -34,14 +34,14 @@ for mode in bf16 bf16x6; do
   python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_$mode" "$O/pmc_fetch_$mode" "$O/pmc_write_$mode" > "$O/pmc_summary_$mode.txt" 2>&1
 done
 SRC="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024"
-K="iefvad_gemm_bf16_w256_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_fused_bf16_kernel|iefvad_outproj_ln_chain_bf16_kernel"
+K="iefvad_inproj_chain_f32in_kernel|iefvad_inproj_chain_bf16_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_chain_bf16_kernel|iefvad_outproj_ln_chain_bf16_kernel"
 # algorithmic bytes of the six projection launches of a 262,144-row pass (bf16 mode, outputs=scores), KB per row, both modalities:
-# in_proj x2: read 3 (bf16 A), write 9 (bf16 q|k|v); out_proj+LN x2: read 3 + 6 (fp32 residual), write 6 fp32 + 3 bf16 (layer 0) / 3 bf16
-# (layer 1); heads+fusion: read 3, write 3 (fp32 z) + 0.1; refinement chain: read 3 (z), write 0.004
+# in_proj x2: read 6 (fp32 rows, layer 0) / 3 (bf16 rows, layer 1), write 9 (bf16 q|k|v); out_proj+LN x2: read 3 + 6 (fp32 residual),
+# write 6 fp32 + 3 bf16 (layer 0) / 3 bf16 (layer 1); heads+fusion: read 3, write 3 (fp32 z) + 0.2; refinement chain: read 3 (z), write 0.004
 python3 "$R/tools/hbm_traffic.py" "$(find "$O/pmc_fetch_bf16" -name '*counter_collection.csv' | head -1)" "$(find "$O/pmc_write_bf16" -name '*counter_collection.csv' | head -1)" \
     "$K" 262144 "$O/gemm_bf16_hbm_traffic.json" "$SRC --compute bf16 (one micro-batch of 1024 chunks = 262144 rows per launch), MI355X, $RND, head $HEAD" \
-    $(python3 -c "print(262144*1024*(3+3+3+6+3+6+3+3)/6, 262144*1024*(9+9+9+3+3.1+0.004)/6)") \
-    "mean over the 6 projection launches of one pass: 2 x in_proj (3 KB/row read, 9 written), 2 x out_proj+LayerNorm (9 read; 9 / 3 written), heads+fusion (3 / 3.1), refinement chain of 2K projections + scorer (3 / 0.004); weights <= 24 MB per launch" > /dev/null 2>&1
+    $(python3 -c "print(262144*1024*(6+3+3+6+3+6+3+3)/6, 262144*1024*(9+9+9+3+3.2+0.004)/6)") \
+    "mean over the 6 projection launches of one pass: 2 x in_proj (6 / 3 KB/row read, 9 written), 2 x out_proj+LayerNorm (9 read; 9 / 3 written), heads+fusion (3 / 3.2), refinement chain of 2K projections + scorer (3 / 0.004); weights <= 24 MB per launch" > /dev/null 2>&1
 K=iefvad_gemm_split_n128_kernel
 python3 "$R/tools/hbm_traffic.py" "$(find "$O/pmc_fetch_bf16x6" -name '*counter_collection.csv' | head -1)" "$(find "$O/pmc_write_bf16x6" -name '*counter_collection.csv' | head -1)" \
     $K 262144 "$O/gemm_split_hbm_traffic.json" "$SRC --compute bf16x6 (262144 rows per launch), MI355X, $RND, head $HEAD" \
