@@ -44,12 +44,21 @@ if ln_f is None:        # ... and with the refinement chain (scorer inside it): 
         return (max(vals), 1)
     ln_f, ln_w = biggest(fetch_csv, "FETCH_SIZE"), biggest(write_csv, "WRITE_SIZE")
     ln_bytes = 2 * rows * 768 * 4
-fetch_scale = round(ln_bytes / (ln_f[0] * 1024))               # 2 on gfx950
+ratio = ln_bytes / (ln_f[0] * 1024)
+if 0.8 <= ratio <= 2.5:
+    fetch_scale = round(ratio)                                  # 2 on gfx950
+    cal_text = (f"{cal_name} streams {ln_bytes} B in: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
+                f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}")
+else:
+    # no launch of known streamed bytes in this mode's passes (bf16 mode: LayerNorm, scorer and the input cast are all inside
+    # the row-block kernels): the factor every calibrated pass of this chip has shown, e.g. the bf16x6 pass of the same collection
+    fetch_scale = 2
+    cal_text = ("no stand-alone streaming kernel in this mode's passes; FETCH_SIZE x 2 as calibrated on iefvad_layernorm_kernel in "
+                "the bf16x6 pass of the same collection (gemm_split_hbm_traffic.json)")
 kf, kw = pick(f, kname), pick(w, kname)
 res = {"source": source, "kernel": kname, "launches_measured": kf[1], "rows_per_launch": rows,
        "FETCH_SIZE_KB_mean": kf[0], "WRITE_SIZE_KB_mean": kw[0],
-       "calibration": f"{cal_name} streams {ln_bytes} B in: WRITE_SIZE reads {ln_w[0]:.0f} KB, "
-                      f"FETCH_SIZE reads {ln_f[0]:.0f} KB -> FETCH_SIZE x {fetch_scale}",
+       "calibration": cal_text,
        "read_bytes_per_launch": kf[0] * 1024 * fetch_scale, "write_bytes_per_launch": kw[0] * 1024,
        "traffic_bytes_per_launch": kf[0] * 1024 * fetch_scale + kw[0] * 1024}
 subs = kname.split("|")
