@@ -1687,6 +1687,27 @@ extern "C" int iefvad_loss_forward(const float* logits, const float* image_mu, c
 // ------------------------------------------------------------------------------------------------
 // host side of the whole-video path: gather the videos' rows into one (pinned) staging buffer
 // ------------------------------------------------------------------------------------------------
+// Copy with non-temporal stores: the destination is a pinned staging buffer that only the DMA engine reads next, so its lines need
+// neither be fetched for ownership nor stay in the CPU caches (a plain memcpy of the 890 MB of an XD-sized list moves 2.7 GB
+// through the memory controllers, this 1.8 GB -- and the H2D copy of the previous batch is reading the same DRAM meanwhile).
+static void stream_copy(char* d, const char* s, size_t n) {
+    typedef long long v4 __attribute__((vector_size(32)));
+    typedef long long v4u __attribute__((vector_size(32), aligned(1)));
+    if (n < 4096) { memcpy(d, s, n); return; }
+    size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+    memcpy(d, s, head);
+    d += head; s += head; n -= head;
+    const size_t body = n & ~(size_t)127;
+    for (size_t i = 0; i < body; i += 128) {
+        const v4 a = *(const v4u*)(s + i), b = *(const v4u*)(s + i + 32), c = *(const v4u*)(s + i + 64), e = *(const v4u*)(s + i + 96);
+        __builtin_nontemporal_store(a, (v4*)(d + i));
+        __builtin_nontemporal_store(b, (v4*)(d + i + 32));
+        __builtin_nontemporal_store(c, (v4*)(d + i + 64));
+        __builtin_nontemporal_store(e, (v4*)(d + i + 96));
+    }
+    memcpy(d + body, s + body, n - body);
+}
+
 extern "C" int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
     if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather: null argument");
     if (count == 0) return 0;
@@ -1701,7 +1722,8 @@ extern "C" int iefvad_host_gather(void* dst, const void* const* srcs, const size
     if (total < ((size_t)4 << 20)) nt = 1;               // a few MB: one thread is done before a second one has started
     auto run = [&](int64_t a, int64_t b) {
         for (int64_t i = a; i < b; ++i)
-            if (nbytes[i]) memcpy((char*)dst + off[(size_t)i], srcs[i], nbytes[i]);
+            if (nbytes[i]) stream_copy((char*)dst + off[(size_t)i], (const char*)srcs[i], nbytes[i]);
+        __builtin_ia32_sfence();                          // the non-temporal stores are globally visible before the caller starts a DMA
     };
     if (nt == 1) {
         run(0, count);

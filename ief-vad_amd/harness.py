@@ -10,6 +10,9 @@ The model is any callable with the reference's `model(img, ev, padding_mask, tex
 """
 from __future__ import annotations
 
+import collections
+import concurrent.futures
+import contextlib
 import csv
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -297,8 +300,9 @@ class _RowStager:
             b = self.bufs[slot][m]
         return b
 
-    def upload(self, imgs, evs, dt):
-        """imgs / evs: per video [len, D] host tensors (views are fine).  Returns two [sum(len), D] device tensors."""
+    def stage(self, imgs, evs, dt):
+        """Host half of `upload`: the rows of all videos into the next pinned slot.  Touches no stream (it only waits for the
+        slot's previous copy), so a worker thread can run it while the caller's thread enqueues the previous batch."""
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.bufs)
         if self.events[slot] is not None:
@@ -326,11 +330,20 @@ class _RowStager:
                 hosts[0][off:off + l].copy_(imgs[i])
                 hosts[1][off:off + l].copy_(evs[i])
                 off += l
+        return slot, hosts
+
+    def send(self, staged):
+        """Device half: one asynchronous copy per modality on the current stream.  Returns two [sum(len), D] device tensors."""
+        slot, hosts = staged
         out = [h.to(self.device, non_blocking=True) for h in hosts]
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.events[slot] = ev
         return out[0], out[1]
+
+    def upload(self, imgs, evs, dt):
+        """imgs / evs: per video [len, D] host tensors (views are fine).  Returns two [sum(len), D] device tensors."""
+        return self.send(self.stage(imgs, evs, dt))
 
 
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
@@ -388,13 +401,46 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         for s in streams:
             s.wait_stream(torch.cuda.current_stream(device))     # e.g. a `model.to(device)` still in flight
     nflush = 0
+    # packed valid-row loop: the staging copy of batch k + 1 (host threads inside the library, no GIL) runs on a worker
+    # thread while this thread sends batch k and enqueues its forward; batches complete in order
+    inflight: collections.deque = collections.deque()
+    stage_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if ragged else None
+
+    def run_oldest():
+        nonlocal total
+        fut, k, lens = inflight.popleft()
+        staged = fut.result()
+        ctx = torch.cuda.stream(streams[k]) if nl > 1 else contextlib.nullcontext()
+        with ctx:
+            img, ev = stagers[k].send(staged)
+            out = models[k].forward_videos(img, ev, lens, nan_to_num=True)
+        dev_prob.append(out['logits'])
+        dev_wi.append(out['w_i_mean'])
+        dev_we.append(out['w_e_mean'])
+        off = total
+        for n in lens:
+            spans.append((off, n))
+            off += n
+        total = off
 
     def flush():
-        nonlocal nflush
+        nonlocal nflush, pend, pend_chunks
         if not pend:
             return
         k = nflush % nl
         nflush += 1
+        if ragged:
+            dts = {p[0].dtype for p in pend} | {p[1].dtype for p in pend}
+            dt = torch.float32 if len(dts) > 1 else pend[0][0].dtype
+            if len(dts) > 1:      # a narrower video is widened at staging: its own dtype's inf -> max rule applies first (test.py:90-95)
+                pend = [tuple(torch.nan_to_num(t, nan=0.0) if (t.dtype != dt and _has_nan(t)) else t for t in (p[0], p[1])) + (p[2],)
+                        for p in pend]
+            fut = stage_pool.submit(stagers[k].stage, [p[0] for p in pend], [p[1] for p in pend], dt)
+            inflight.append((fut, k, [n for _, _, n in pend]))
+            pend, pend_chunks = [], 0
+            while len(inflight) > 1:
+                run_oldest()
+            return
         if nl > 1:
             with torch.cuda.stream(streams[k]):
                 flush_on(models[k], stagers[k])
@@ -408,23 +454,6 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         # to fp32 here rather than narrowed to the first tensor's type
         dts = {p[0].dtype for p in pend} | {p[1].dtype for p in pend}
         dt = torch.float32 if len(dts) > 1 else pend[0][0].dtype
-        if ragged:
-            if len(dts) > 1:      # a narrower video is widened at staging: its own dtype's inf -> max rule applies first (test.py:90-95)
-                pend = [tuple(torch.nan_to_num(t, nan=0.0) if (t.dtype != dt and _has_nan(t)) else t for t in (p[0], p[1])) + (p[2],)
-                        for p in pend]
-            img, ev = stager.upload([p[0] for p in pend], [p[1] for p in pend], dt)
-            lens = [n for _, _, n in pend]
-            out = model.forward_videos(img, ev, lens, nan_to_num=True)
-            dev_prob.append(out['logits'])
-            dev_wi.append(out['w_i_mean'])
-            dev_we.append(out['w_e_mean'])
-            off = total
-            for n in lens:
-                spans.append((off, n))
-                off += n
-            total = off
-            pend, pend_chunks = [], 0
-            return
         if stager is not None:
             img, ev = stager.upload([p[0] for p in pend], [p[1] for p in pend], dt)
         else:
@@ -466,6 +495,10 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             if batch_chunks <= 0 or pend_chunks >= batch_chunks:
                 flush()
         flush()
+        while inflight:
+            run_oldest()
+        if stage_pool is not None:
+            stage_pool.shutdown(wait=True)
         if nl > 1:
             for s in streams:
                 torch.cuda.current_stream(device).wait_stream(s)
