@@ -217,13 +217,17 @@ def _unpack_item(item, maxlen, dataset, label_map):
 
 def _unpack_rows(item, maxlen, dataset, label_map):
     """One DataLoader item (batch_size=1, chunked and zero padded by the loader as the reference's is) reduced to what
-    crosses the boundary in the ragged path: views of its `length` valid rows per modality."""
+    crosses the boundary in the ragged path: per modality the item's own [..., D] tensor, whose first `length` rows are the
+    valid ones (no view is built: two tensor ops per video were a third of the loop's host time on short videos)."""
     cls = item[2][0] if isinstance(item[2], (list, tuple)) else item[2]
     if dataset == 'xd' and label_map is not None:
         cls = label_map[cls.split('-')[0]]            # xd_test.py:68
     length = int(item[3])
-    img = item[0].reshape(-1, item[0].shape[-1])[:length]
-    ev = item[1].reshape(-1, item[1].shape[-1])[:length]
+    img, ev = item[0], item[1]
+    if not img.is_contiguous():
+        img = img.contiguous()
+    if not ev.is_contiguous():
+        ev = ev.contiguous()
     return img, ev, cls, length
 
 
@@ -300,15 +304,17 @@ class _RowStager:
             b = self.bufs[slot][m]
         return b
 
-    def stage(self, imgs, evs, dt):
+    def stage(self, imgs, evs, dt, lens=None):
         """Host half of `upload`: the rows of all videos into the next pinned slot.  Touches no stream (it only waits for the
-        slot's previous copy), so a worker thread can run it while the caller's thread enqueues the previous batch."""
+        slot's previous copy), so a worker thread can run it while the caller's thread enqueues the previous batch.
+        `lens` given: imgs / evs are contiguous [..., D] tensors whose FIRST lens[i] rows are taken."""
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.bufs)
         if self.events[slot] is not None:
             self.events[slot].synchronize()
-        D = int(imgs[0].shape[1])
-        lens = [int(p.shape[0]) for p in imgs]
+        D = int(imgs[0].shape[-1])
+        if lens is None:
+            lens = [int(p.shape[0]) for p in imgs]
         total = sum(lens)
         esize = torch.empty(0, dtype=dt).element_size()
         hosts = [self._buffer(slot, m, total * D * esize)[:total * D * esize].view(dt).view(total, D) for m in range(2)]
@@ -327,8 +333,8 @@ class _RowStager:
         else:                                                     # a widened (mixed-dtype) batch: torch casts while copying
             off = 0
             for i, l in enumerate(lens):
-                hosts[0][off:off + l].copy_(imgs[i])
-                hosts[1][off:off + l].copy_(evs[i])
+                hosts[0][off:off + l].copy_(imgs[i].reshape(-1, D)[:l])
+                hosts[1][off:off + l].copy_(evs[i].reshape(-1, D)[:l])
                 off += l
         return slot, hosts
 
@@ -341,9 +347,10 @@ class _RowStager:
         self.events[slot] = ev
         return out[0], out[1]
 
-    def upload(self, imgs, evs, dt):
-        """imgs / evs: per video [len, D] host tensors (views are fine).  Returns two [sum(len), D] device tensors."""
-        return self.send(self.stage(imgs, evs, dt))
+    def upload(self, imgs, evs, dt, lens=None):
+        """imgs / evs: per video [len, D] host tensors (views are fine), or with `lens` contiguous [..., D] tensors of which the
+        first lens[i] rows count.  Returns two [sum(len), D] device tensors."""
+        return self.send(self.stage(imgs, evs, dt, lens))
 
 
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
@@ -435,8 +442,9 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             if len(dts) > 1:      # a narrower video is widened at staging: its own dtype's inf -> max rule applies first (test.py:90-95)
                 pend = [tuple(torch.nan_to_num(t, nan=0.0) if (t.dtype != dt and _has_nan(t)) else t for t in (p[0], p[1])) + (p[2],)
                         for p in pend]
-            fut = stage_pool.submit(stagers[k].stage, [p[0] for p in pend], [p[1] for p in pend], dt)
-            inflight.append((fut, k, [n for _, _, n in pend]))
+            lens = [n for _, _, n in pend]
+            fut = stage_pool.submit(stagers[k].stage, [p[0] for p in pend], [p[1] for p in pend], dt, lens)
+            inflight.append((fut, k, lens))
             pend, pend_chunks = [], 0
             while len(inflight) > 1:
                 run_oldest()

@@ -37,7 +37,7 @@ def main():
     # one pinned pair per batch, staged once
     stagers = [harness._RowStager(dev, slots=1) for _ in range(nb)]
     def stage_all():
-        return [stagers[i].stage([r[0] for r in b], [r[1] for r in b], torch.float32) for i, b in enumerate(batches)]
+        return [stagers[i].stage([r[0] for r in b], [r[1] for r in b], torch.float32, [r[3] for r in b]) for i, b in enumerate(batches)]
     staged = stage_all()
     for st in stagers:
         st.events = [None]

@@ -57,7 +57,7 @@ def main():
         for rep in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            di, de = st.upload(imgs, evs, torch.float32)
+            di, de = st.upload(imgs, evs, torch.float32, lens)
             t_stage = time.perf_counter() - t0
             torch.cuda.synchronize()
             t_h2d = time.perf_counter() - t0
