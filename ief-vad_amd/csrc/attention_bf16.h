@@ -23,6 +23,8 @@ struct AttnBArgs {
     bf16_t* out[2];         // [N, 768] bf16 per modality
     int nchunks;            // chunks per modality in this launch
     const RaggedChunk* chunks;   // *_rows_kernel: row-compressed chunks (common.h); row r of the window = row min(r, valid)
+    int head_major;         // 0: qkv is [N, 2304] as above; 1: [3 (q, k, v)][8 heads][N][96] -- what inproj_chain_bf16.h writes: a
+    int nrows;              //    head's K / V tile is one contiguous 48 KB block (whole 128-byte lines) instead of 192-byte row segments
 };
 
 #define ATTB_KROW 104   // K image row length in bf16 elements (208 B = 13 x 16 B)
@@ -43,7 +45,12 @@ __device__ __forceinline__ void attention_bf16_body(const AttnBArgs& args, bf16_
         if (qhalf * 128 > last) return;              // every query of this half is a pad row: nobody reads its output
     }
 #define ATTB_ROW(r) (RG ? ((r) < last ? (r) : last) : (r))
-    const bf16_t* qkv = args.qkv[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
+    // q / k / v rows of this head: base pointers and the row stride of the layout
+    const int rs = args.head_major ? IEF_DH : 3 * IEF_D;
+    const size_t plane = args.head_major ? (size_t)IEF_H * args.nrows * IEF_DH : (size_t)IEF_D;
+    const bf16_t* qb = args.qkv[mod] + (args.head_major ? ((size_t)head * args.nrows + row0) * IEF_DH : (size_t)row0 * (3 * IEF_D) + head * IEF_DH);
+    const bf16_t* kb = qb + plane;
+    const bf16_t* vb_ = kb + plane;
     bf16_t* out = args.out[mod] + (size_t)row0 * IEF_D + head * IEF_DH;
 
     const int t = threadIdx.x;
@@ -54,7 +61,7 @@ __device__ __forceinline__ void attention_bf16_body(const AttnBArgs& args, bf16_
     // Q fragment (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
     bf16x8 q[6];
     {
-        const bf16_t* qp = qkv + (size_t)ATTB_ROW(q0 + i) * (3 * IEF_D) + 8 * h;
+        const bf16_t* qp = qb + (size_t)ATTB_ROW(q0 + i) * rs + 8 * h;
 #pragma unroll
         for (int s = 0; s < 6; ++s) q[s] = *(const bf16x8*)(qp + 16 * s);
     }
@@ -63,7 +70,7 @@ __device__ __forceinline__ void attention_bf16_body(const AttnBArgs& args, bf16_
     for (int j = 0; j < 12; ++j) {
         const int c = t + 256 * j;
         const int row = c / 12, ch = c - row * 12;
-        *(bf16x8*)(kv + row * ATTB_KROW + ch * 8) = *(const bf16x8*)(qkv + (size_t)ATTB_ROW(row) * (3 * IEF_D) + IEF_D + ch * 8);
+        *(bf16x8*)(kv + row * ATTB_KROW + ch * 8) = *(const bf16x8*)(kb + (size_t)ATTB_ROW(row) * rs + ch * 8);
     }
     __syncthreads();
 
@@ -74,7 +81,7 @@ __device__ __forceinline__ void attention_bf16_body(const AttnBArgs& args, bf16_
     for (int j = 0; j < 12; ++j) {
         const int c = t + 256 * j;
         const int row = c / 12, ch = c - row * 12;
-        vstage[j] = *(const bf16x8*)(qkv + (size_t)ATTB_ROW(row) * (3 * IEF_D) + 2 * IEF_D + ch * 8);
+        vstage[j] = *(const bf16x8*)(vb_ + (size_t)ATTB_ROW(row) * rs + ch * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 

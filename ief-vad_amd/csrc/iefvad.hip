@@ -850,6 +850,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 for (int m = 0; m < 2; ++m) { ab.qkv[m] = qkvb[m]; ab.out[m] = attb[m]; }
                 ab.nchunks = nb;
                 ab.chunks = enc_rows_mode ? rg->d_chunks : nullptr;
+                ab.head_major = ip_chain ? 1 : 0;
+                ab.nrows = rows;
                 if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_bf16_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
                 else hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
             } else {

@@ -26,7 +26,7 @@ struct InProjChainProblem {
     const void* A;           // [M, 768] rows: fp32 (A32) or bf16
     const char* stream;      // iefvad_wstream_pack_kernel(in_proj_weight, 3 passes)
     const float* bias;       // [2304]
-    bf16_t* C;               // [M, 2304] bf16: q | k | v
+    bf16_t* C;               // bf16 q | k | v, head-major: [3][8 heads][M][96] (AttnBArgs.head_major): a wave's 96 columns of a pass are one head
 };
 struct InProjChainArgs {
     InProjChainProblem p[2]; // one per modality (blockIdx.y)
@@ -138,7 +138,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
         // ---- epilogue of the pass: (acc + bias) * scale -> bf16, 16 rows at a time through the wave's private tile.
         // accumulator tile (a, b): lane (m, q) holds row 16 a + m, columns 16 b + 4 q .. + 3
         const float sc = pass == 0 ? args.alpha : 1.f;
-        bf16_t* cbase = P.C + (size_t)m0 * (3 * IEF_D) + IEF_D * pass + 96 * wave;
+        bf16_t* cbase = P.C + ((size_t)(pass * IEF_H + wave) * args.M + m0) * IEF_DH;      // plane (pass, head = wave), contiguous 12 KB per wave
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             bf16_t* stage = stage0 + (a & 1) * (IC_STAGE_BYTES / 2);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void inproj_chain_body(const InProjChainArgs& args, c
             for (int i = 0; i < 3; ++i) {
                 const int id = lane + 64 * i, row = id / 12, ch = id - row * 12;
                 const bf16x8 w = *(const bf16x8*)(stage + row * IC_STAGE_LD + 8 * ch);
-                GB2_STORE((bf16x8*)(cbase + (size_t)(16 * a + row) * (3 * IEF_D) + 8 * ch), w);
+                GB2_STORE((bf16x8*)(cbase + (size_t)(16 * a + row) * IEF_DH + 8 * ch), w);
             }
         }
         IC_STAMP(3 + 2 * pass);
