@@ -1095,6 +1095,9 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             ca.z_out = out->fused ? z : nullptr;        // in place: a workgroup reads its 64 rows before it writes them
             ca.logits = logits;
             ca.M = rows; ca.K = K; ca.lambda = c.lambda_ref; ca.wave_stride = (unsigned)chain_wave_stride_bytes(K);
+#ifdef RC_DIAG
+            { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_RC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ca.diag = dg; }
+#endif
             hipEvent_t e = tm.begin(ST_REFINE);
             hipLaunchKernelGGL(iefvad_refine_chain_bf16_kernel, dim3(rows / RC_BM), dim3(64 * RC_NW), RC_LDS_BYTES, stream, ca);
             tm.end(e);

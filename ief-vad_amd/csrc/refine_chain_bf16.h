@@ -106,7 +106,13 @@ struct ChainArgs {
     int K;                   // >= 1
     float lambda;
     unsigned wave_stride;    // bytes between the waves' streams
+    unsigned long long* diag; // RC_DIAG builds only: 16 s_memtime stamps per workgroup over projections 2 and 3 (tools/rowblock_diag.py chain)
 };
+#ifdef RC_DIAG
+#define RC_STAMP(i) do { if (args.diag && t == 0 && (g == 2 || g == 3)) args.diag[(size_t)blockIdx.x * 16 + (g - 2) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RC_STAMP(i)
+#endif
 
 __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < RC_NBP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            RC_STAMP(3 * pass);
 #if RC_KUNROLL == RC_KT
 #pragma unroll
 #else
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
             }
 
             // ---- the pass's epilogue; its bias pieces are the next ones of the ring
+            RC_STAMP(3 * pass + 1);
             asm volatile("" : "+v"(mo), "+v"(qo));
             f32x4 bias[RC_NBP];
 #pragma unroll
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                 ++p;
             }
             if (pass == RC_NPASS - 1) GB2_BARRIER();      // every wave is done reading the image: it may be rewritten
+            RC_STAMP(3 * pass + 2);
             if (first) {
 #pragma unroll
                 for (int b = 0; b < RC_NBP; ++b)
@@ -249,8 +258,10 @@ __global__ __launch_bounds__(512, 2) void iefvad_refine_chain_bf16_kernel(ChainA
                     }
             }
             if (pass == RC_NPASS - 1) {
+                RC_STAMP(6);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 GB2_BARRIER();                            // the image holds the next operand
+                RC_STAMP(7);
             }
         }
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Phase breakdown of a row-block kernel from in-kernel s_memtime stamps (a -DHC_DIAG / -DIC_DIAG build of the library,
-IEFVAD_LIB=build/libiefvad_<x>diag.so).  Usage: rowblock_diag.py heads|inproj.  The stamps go to a buffer of their own; no
+"""Phase breakdown of a row-block kernel from in-kernel s_memtime stamps (a -DHC_DIAG -DIC_DIAG -DRC_DIAG build of the library,
+IEFVAD_LIB=build/libiefvad_<x>diag.so).  Usage: rowblock_diag.py heads|inproj|chain.  The stamps go to a buffer of their own; no
 output depends on them; the LAST launch of the kernel in the forward is what remains in the buffer."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,8 @@ PH = {"heads": (3 * (B * 256 // 64), "IEFVAD_HC_DIAG_PTR",
                  "phase 2 main loop (mu_e, logvar_e)", "epilogue (fusion in registers, stores)"]),
       "inproj": (2 * (B * 256 // 64), "IEFVAD_IC_DIAG_PTR",
                  ["entry -> image ready", "pass q main loop", "pass q epilogue", "pass k main loop", "pass k epilogue",
-                  "pass v main loop", "pass v epilogue"])}[which]
+                  "pass v main loop", "pass v epilogue"]),
+      "chain": (2 * (B * 256 // 64), "IEFVAD_RC_DIAG_PTR", None)}[which]
 buf = torch.zeros(PH[0] * 8, dtype=torch.int64, device="cuda:0")
 os.environ[PH[1]] = str(buf.data_ptr())
 import iefvad_amd
@@ -30,6 +31,18 @@ with torch.no_grad():
     for _ in range(3):
         m(x, y, None, None, None)
 torch.cuda.synchronize()
+if which == "chain":
+    d = buf.cpu().numpy().reshape(-1, 16)[: B * 256 // 64].astype(np.float64)
+    names = ["pass 0 main loop", "pass 0 bias pieces", "pass 0 epilogue (park / z update) + zeroing", "pass 1 main loop", "bias + barrier (image free)",
+             "pass 1 epilogue (image rewritten)", "lgkmcnt + barrier (image ready)"]
+    for gi, gn in ((0, "projection 2 (W1: relu -> h)"), (1, "projection 3 (W2: z update)")):
+        dd = np.diff(d[:, 8 * gi:8 * gi + 8], axis=1)
+        print(f"chain, {gn}: {d.shape[0]} workgroups, wave 0's s_memtime ticks per phase: median / p10 / p90")
+        for i, name in enumerate(names):
+            print(f"  {name:44s} {np.median(dd[:, i]):9.0f} {np.percentile(dd[:, i], 10):9.0f} {np.percentile(dd[:, i], 90):9.0f}")
+        print(f"  {'whole projection':44s} {np.median(d[:, 8 * gi + 7] - d[:, 8 * gi]):9.0f}")
+    print(f"  W1 start -> W2 start {np.median(d[:, 8] - d[:, 0]):9.0f}")
+    sys.exit(0)
 n = len(PH[2])
 d = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
 dd = np.diff(d[:, :n + 1], axis=1)
