@@ -65,6 +65,8 @@ struct iefvad_handle {
     char* iproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: in_proj weights in per-wave fragment order, q | k | v passes (inproj_chain_bf16.h)
     char* heads_stream;    // bf16 mode: the four head matrices in per-wave fragment order (heads_chain_bf16.h)
     bool heads_v1;         // IEFVAD_HEADS_V1=1: bf16 mode's fused heads + fusion on the 256 x 64 ring kernel (heads_fused_bf16.h)
+    int chain_min_blocks;  // bf16 mode: the refinement chain kernel takes a micro-batch from this many 64-row blocks on (IEFVAD_CHAIN_MIN_BLOCKS overrides)
+    int rowblock_min_wgs;  // bf16 mode: the row-block kernels take a projection from this many workgroups on (IEFVAD_ROWBLOCK_MIN_WGS overrides)
     bool no_inproj_chain;  // IEFVAD_NO_INPROJ_CHAIN=1: bf16 mode's in_proj on the 256 x 256 ring kernel (and the stand-alone cast in front of it)
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
     bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
@@ -170,6 +172,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     { const char* v = getenv("IEFVAD_DENSE_ENCODER"); h->dense_encoder = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_NO_INPROJ_CHAIN"); h->no_inproj_chain = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_HEADS_V1"); h->heads_v1 = v && v[0] == '1'; }
+    { const char* v = getenv("IEFVAD_ROWBLOCK_MIN_WGS"); h->rowblock_min_wgs = (v && atoi(v) > 0) ? atoi(v) : 128; }      // tools/rowblock_threshold_probe.py
+    { const char* v = getenv("IEFVAD_CHAIN_MIN_BLOCKS"); h->chain_min_blocks = (v && atoi(v) > 0) ? atoi(v) : 4; }         // one chunk: 4 blocks take one block time, 2K launches more
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -733,7 +737,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         }
 
         // bf16 mode, full grids: in_proj on the row-block kernel (inproj_chain_bf16.h); its first layer reads the fp32 rows
-        const bool ip_chain = bf && !h->no_inproj_chain && rows % IC_BM == 0 && (rows / IC_BM) * 2 >= 256;
+        const bool ip_chain = bf && !h->no_inproj_chain && rows % IC_BM == 0 && (rows / IC_BM) * 2 >= h->rowblock_min_wgs;
         // 0. inputs: `.to(torch.float)` (imf_vad.py:41-42); bf16 mode also needs the bf16 operand copy (unless ip_chain)
         const bool need_xb0 = bf && !ip_chain;
         const float* cur[2];
@@ -878,7 +882,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             HIP_TRY(hipGetLastError());
 
             // out_proj + residual + LayerNorm(s) in one row-owning kernel (bf16 mode, full grids): outproj_ln_bf16.h
-            const bool ln_fused = bf && !h->no_ln_fusion && rows % OL_BM == 0 && (rows / OL_BM) * 2 >= 256;
+            const bool ln_fused = bf && !h->no_ln_fusion && rows % OL_BM == 0 && (h->ol_v1 ? (rows / OL_BM) * 2 >= 256 : (rows / OC_BM) * 2 >= h->rowblock_min_wgs);
             if (ln_fused && !h->ol_v1) {
                 // second design: 64-row blocks on the refinement chain's structure (outproj_ln_chain_bf16.h); same bits
                 OutLnChainArgs oa;
@@ -991,11 +995,11 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 
         // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion, heads_fused_bf16.h.  The four
         // head tensors are stored only if the caller asked for them.
-        const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= 256;
+        const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= (h->heads_v1 ? 256 : h->rowblock_min_wgs);
         // 4 + 5 in one kernel (bf16 mode, full grids): the K refinement steps and the scorer with the state on chip, refine_chain_bf16.h
-        const bool chain = bf && K > 0 && !h->no_chain && h->chain_stream && rows % RC_BM == 0 && rows / RC_BM >= 256;
+        const bool chain = bf && K > 0 && !h->no_chain && h->chain_stream && rows % RC_BM == 0 && rows / RC_BM >= h->chain_min_blocks;
         // second design: 64-row blocks on the row-block structure (heads_chain_bf16.h); same bits except the order of the row sums
-        const bool heads_rows = heads_fused && !h->heads_v1 && h->heads_stream && rows % HC_BM == 0 && (rows / HC_BM) * HC_THIRDS >= 256;
+        const bool heads_rows = heads_fused && !h->heads_v1 && h->heads_stream && rows % HC_BM == 0 && (rows / HC_BM) * HC_THIRDS >= h->rowblock_min_wgs;
         if (heads_rows) {
             HeadsChainArgs ha;
             memset(&ha, 0, sizeof(ha));

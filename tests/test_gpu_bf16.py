@@ -108,7 +108,7 @@ def test_bf16_scores_mode_and_microbatch_bit_identical():
                                                        ("full", False, 3, False), ("full", False, 3, True), ("scores", False, 2, True)])
 def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypatch, outputs, overflow, L, ol_v1):
     """bf16 mode runs the heads of both modalities and the fusion as ONE kernel once a micro-batch fills the chip
-    (csrc/heads_fused_bf16.h; >= 22 chunks), and out_proj + residual + LayerNorm(s) as one row-owning kernel (>= 64 chunks:
+    (csrc/heads_chain_bf16.h from 11 chunks on), and out_proj + residual + LayerNorm(s) as one row-owning kernel (from 16 chunks:
     csrc/outproj_ln_chain_bf16.h, 64-row blocks on the refinement chain's structure; `ol_v1`: the first design,
     csrc/outproj_ln_bf16.h, IEFVAD_OL_V1=1).  Same k order, same LayerNorm / fusion code: every output must equal the
     unfused path bit for bit (IEFVAD_NO_HEADS_FUSION=1, IEFVAD_NO_LN_FUSION=1 at model creation), the row means of the
@@ -149,7 +149,7 @@ def test_fused_heads_kernel_equals_heads_projection_plus_fusion_kernel(monkeypat
                                              (5, 0.5, "scores", 192), (10, 0.5, "full", 128)])
 def test_refinement_chain_kernel_equals_the_2k_launch_path(monkeypatch, K, lam, outputs, B):
     """bf16 mode runs the K refinement steps AND the scorer (imf_vad.py:146-150) as ONE kernel with the state on chip once a
-    micro-batch has >= 256 blocks of 64 rows (csrc/refine_chain_bf16.h): fp32 z in registers, one aliased bf16 z / h image in
+    micro-batch is a whole chunk or more (csrc/refine_chain_bf16.h; the tests below use full grids): fp32 z in registers, one aliased bf16 z / h image in
     LDS, per-wave LDS-DMA weight streams.  Same products in the same k order, same epilogue arithmetic, the scorer kernel's
     own reduction: `fused` and `logits` must equal the 2K-launch path bit for bit (IEFVAD_NO_CHAIN=1 at model creation).
     B = 192 with micro_batch = 128 exercises a second, smaller pass (64 chunks) through the same handle."""
@@ -169,7 +169,7 @@ def test_refinement_chain_kernel_equals_the_2k_launch_path(monkeypatch, K, lam, 
 
 @pytest.mark.parametrize("outputs,overflow,B", [("full", False, 64), ("scores", False, 40), ("full", True, 64)])
 def test_heads_row_block_kernel_equals_the_ring_kernel(monkeypatch, outputs, overflow, B):
-    """bf16 mode, >= 22 chunks: heads + fusion run on the row-block kernel (csrc/heads_chain_bf16.h): 64 rows resident as an
+    """bf16 mode, >= 11 chunks (128 workgroups): heads + fusion run on the row-block kernel (csrc/heads_chain_bf16.h): 64 rows resident as an
     LDS image (x_i, then x_e), a wave streams the four head matrices of its 32 columns and fuses in registers.  Same products
     in the same k order and the same fusion code as the 256 x 64 ring kernel (csrc/heads_fused_bf16.h, IEFVAD_HEADS_V1=1 at
     model creation): every output bit for bit, the row means of the weights to fp32 rounding (24 partial sums instead of 12).
@@ -200,12 +200,12 @@ def test_heads_row_block_kernel_equals_the_ring_kernel(monkeypatch, outputs, ove
 
 @pytest.mark.parametrize("L,in_dtype,B", [(2, np.float32, 64), (3, np.float16, 64), (2, np.float32, 96)])
 def test_inproj_row_block_kernel_equals_the_ring_kernel(monkeypatch, L, in_dtype, B):
-    """bf16 mode, >= 64 chunks: in_proj runs on the row-block kernel (csrc/inproj_chain_bf16.h): a workgroup keeps 64 rows as
+    """bf16 mode, >= 16 chunks (128 workgroups): in_proj runs on the row-block kernel (csrc/inproj_chain_bf16.h): a workgroup keeps 64 rows as
     one LDS image, every wave streams its own 96 columns of q, k and v; the first layer reads the fp32 rows and rounds them to
     bf16 itself (no cast kernel, no bf16 copy of the inputs).  Same products in the same k order, the ring kernel's epilogue:
     every output must equal the ring-kernel path (IEFVAD_NO_INPROJ_CHAIN=1 at model creation) bit for bit.  NaN / inf rows
-    included; fp16 inputs take the widening cast first; B = 96 with micro_batch = 64 runs a second, smaller pass (32 chunks:
-    the ring kernel) through the same handle."""
+    included; fp16 inputs take the widening cast first; B = 96 with micro_batch = 64 runs a second, smaller pass (32 chunks)
+    through the same handle."""
     sd = synth.make_state_dict(13, 768, L, 3)
     img, ev = synth.make_inputs(36, B)
     img[2, 100, 9] = np.nan
