@@ -593,11 +593,13 @@ static int launch_gemm_b(const GemmBArgs& a, int nz, hipStream_t stream, Timer& 
 }
 
 // BF16X6: the split kernel (128 x 128 tiles, two workgroups per CU; tools/gemm_tune_split: +5..8 % over the 128 x 256 /
-// one-workgroup configuration, same bits) takes the projection when its grid fills the chip; smaller problems run on the
-// fp32 kernels (launch_gemm)
+// one-workgroup configuration, same bits) takes a micro-batch's projections from 72 workgroups of a 768-wide projection on
+// (6 chunks: measured crossover, B = 24 forward 3.55 -> 1.97 ms; it was 512 workgroups, "fills the chip", until the end of
+// round 3); smaller problems run on the fp32 kernels (launch_gemm)
 static const int kSplitBN = GS_BN_OF(2);
+static int g_split_min_wgs = [] { const char* v = getenv("IEFVAD_SPLIT_MIN_WGS"); return (v && atoi(v) > 0) ? atoi(v) : 72; }();      // 6 chunks; tools/split_threshold_probe.py
 static bool split_eligible(int M, int N, int K, int nz) {
-    return M % GS_BM == 0 && N % kSplitBN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / kSplitBN) * nz >= 512;
+    return M % GS_BM == 0 && N % kSplitBN == 0 && K % 64 == 0 && K >= 64 && (M / GS_BM) * (N / kSplitBN) * nz >= g_split_min_wgs;
 }
 
 static int launch_gemm_split(const GemmBArgs& a, int nz, hipStream_t stream, Timer& tm, int stage, bool f16 = false) {
