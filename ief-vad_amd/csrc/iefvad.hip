@@ -521,27 +521,35 @@ static void release_events(iefvad_handle* h) {
 
 // A/B switch for tests and tools (IEFVAD_NO_TINY_GEMM=1): route small problems to the 64x64 kernel as before round 2
 static const bool g_force_no_tiny = [] { const char* v = getenv("IEFVAD_NO_TINY_GEMM"); return v && v[0] == '1'; }();
+// grid-size rules of the fp32 tilings (tools/f32_threshold_probe.py): IEFVAD_F32_RULES="tiny_max_blocks64,t256_min_blocks,small_max_blocks128"
+static int g_f32_rules[3] = {320, 1536, 1024};      // were {320, 256, 256} ("when the grid fills the chip") until measured: B = 48 forward 6.7 -> 5.5 ms
+static const bool g_f32_rules_read = [] {
+    const char* v = getenv("IEFVAD_F32_RULES");
+    if (v) (void)sscanf(v, "%d,%d,%d", &g_f32_rules[0], &g_f32_rules[1], &g_f32_rules[2]);
+    return true;
+}();
 
 static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm, int stage) {
     if (a.M % GEMM_BM || a.N % GEMM_BN || a.K % GEMM_BK)
         return fail("gemm: shape M=%d N=%d K=%d not a multiple of the %dx%dx%d tile", a.M, a.N, a.K, GEMM_BM, GEMM_BN,
                     GEMM_BK);
     // Four tilings of the same contraction, bit-identical to each other (same k order per output element):
-    //   128x256 / 3-slot ring (iefvad_gemm_f32_t256_kernel)  the throughput kernel, when its grid fills the chip;
+    //   128x256 / 3-slot ring (iefvad_gemm_f32_t256_kernel)  the throughput kernel, from 6 blocks per CU on (it wins 2 % at a full
+    //                                                         micro-batch and loses 10-18 % between 1 and 4 blocks per CU);
     //   128x128 / double buffer (iefvad_gemm_f32_kernel)      mid-size grids or N not a multiple of 256;
-    //   64x64 (iefvad_gemm_f32_small_kernel)                  small M: 4x the blocks, a quarter of the MFMA chain;
+    //   64x64 (iefvad_gemm_f32_small_kernel)                  up to 4 blocks of 128x128 per CU: 4x the blocks, a quarter of the MFMA chain;
     //   32x32 on 16x16x4 MFMAs (iefvad_gemm_f32_tiny_kernel)  the per-video pattern (B = 1 .. a few chunks): 16x the
     //                                                         blocks, a wave's chain is 3.2 us instead of 10 / 41 us.
     const int blocks128 = (a.M / GEMM_BM) * (a.N / GEMM_BN) * nz;
     const int blocks64 = (a.M / GEMS_BM) * (a.N / GEMS_BN) * nz;
     const bool t256_ok = (a.N % GB2_BN == 0) && (a.K % 16 == 0) && (a.K >= 32);
     const int blocks256 = t256_ok ? (a.M / GB2_BM) * (a.N / GB2_BN) * nz : 0;
-    const bool tiny = blocks64 < 320 && a.K % 64 == 0 && !g_force_no_tiny;      // < 1.25 blocks of 64x64 per CU: the chain, not the chip, bounds it
+    const bool tiny = blocks64 < g_f32_rules[0] && a.K % 64 == 0 && !g_force_no_tiny;      // < 1.25 blocks of 64x64 per CU: the chain, not the chip, bounds it
     hipEvent_t e = tm.begin(stage);
     if (tiny) {
         dim3 grid((a.M / GEMT_BM) * (a.N / GEMT_BN), 1, nz);
         hipLaunchKernelGGL(iefvad_gemm_f32_tiny_kernel, grid, dim3(256), 0, stream, a);
-    } else if (blocks256 >= 256) {
+    } else if (blocks256 >= g_f32_rules[1]) {
         GemmBArgs b;
         memset(&b, 0, sizeof(b));
         b.M = a.M; b.N = a.N; b.K = a.K; b.lda = a.lda; b.ldc = a.ldc; b.epi = a.epi; b.alpha = a.alpha; b.qcols = a.qcols;
@@ -551,7 +559,7 @@ static int launch_gemm(const GemmArgs& a, int nz, hipStream_t stream, Timer& tm,
         }
         dim3 grid((a.M / GB2_BM) * (a.N / GB2_BN), 1, nz);
         hipLaunchKernelGGL(iefvad_gemm_f32_t256_kernel, grid, dim3(256), GB2_LDS_BYTES, stream, b);
-    } else if (blocks128 < 256) {
+    } else if (blocks128 < g_f32_rules[2]) {
         dim3 grid((a.M / GEMS_BM) * (a.N / GEMS_BN), 1, nz);
         hipLaunchKernelGGL(iefvad_gemm_f32_small_kernel, grid, dim3(256), 0, stream, a);
     } else {
