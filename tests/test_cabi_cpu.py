@@ -142,5 +142,13 @@ def test_host_gather_concatenates_rows_without_a_gpu(lib):
         nb = (C.c_size_t * len(parts))(*sizes)
         assert lib.iefvad_host_gather(dst.ctypes.data, ptrs, nb, len(parts), threads) == 0, L.last_error()
         assert np.array_equal(dst[:-8], np.concatenate(parts)) and (dst[-8:] == 0xEE).all()
+    # misaligned sources and destination (the copy uses 32-byte non-temporal stores behind an alignment head)
+    base = rng.integers(0, 255, (1 << 20) + 64, dtype=np.uint8)
+    parts = [base[3:3 + 70001], base[17:17 + 4097], base[1:1 + (1 << 19)]]
+    dst = np.full(sum(p.size for p in parts) + 13 + 8, 0xEE, np.uint8)
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in parts])
+    nb = (C.c_size_t * 3)(*[p.size for p in parts])
+    assert lib.iefvad_host_gather(dst.ctypes.data + 13, ptrs, nb, 3, 2) == 0, L.last_error()
+    assert np.array_equal(dst[13:-8], np.concatenate(parts)) and (dst[-8:] == 0xEE).all() and (dst[:13] == 0xEE).all()
     assert lib.iefvad_host_gather(None, None, None, 0, 4) == 0
     assert lib.iefvad_host_gather(None, None, None, 3, 4) != 0 and "null" in L.last_error()
