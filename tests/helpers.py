@@ -19,7 +19,7 @@ TOL_SIGMOID = 2e-6
 
 
 def golden_cases(big=False):
-    """Reference-generated forward cases; `big` selects the ones at a split-kernel batch size (B >= 43)."""
+    """Reference-generated forward cases; `big` selects the ones at a full-grid split-kernel batch size (B = 48; the split kernels take over from 6 chunks)."""
     names = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "fwd_*.npz")))
     return [n for n in names if n.startswith("b48") == big]
 

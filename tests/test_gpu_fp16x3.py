@@ -228,7 +228,7 @@ def test_input_scale_3000_is_ill_conditioned_in_every_arithmetic(compute):
 @pytest.mark.parametrize("compute", ["f32", "bf16x6", "fp16x3"])
 @pytest.mark.parametrize("name", H.golden_cases(big=True))
 def test_split_sized_batch_against_the_reference_fixture(name, compute):
-    """The split kernels (B >= 43 chunks) compared DIRECTLY with outputs the reference model itself produced at B = 48
+    """The split kernels (used from 6 chunks on) compared DIRECTLY with outputs the reference model itself produced at B = 48
     (tests/golden/fwd_b48_*.npz, written by tests/golden/make_golden.py from /root/reference/model/imf_vad.py), not only
     with the oracle: every chunk's logits / sigmoid / weight means, the 768-d outputs of three chunks, fp32 gates."""
     g, cfg, sd, img, ev = H.load_case(name)
