@@ -113,8 +113,8 @@ def test_scores_only_outputs_equal_full_outputs():
 
 
 def test_small_batches_run_on_the_fp32_kernels():
-    """Documented dispatch: a batch whose grids would not fill the chip uses the fp32 MFMA kernels (bit-identical to
-    compute="f32"); K=5 / Gaussian variant and fp16 inputs go through the split path at B = 48."""
+    """Documented dispatch: a batch below 6 chunks uses the fp32 MFMA kernels (bit-identical to compute="f32"); K=5 /
+    Gaussian variant and fp16 inputs go through the split path at B = 48."""
     sd = synth.make_state_dict(1)
     img, ev = synth.make_inputs(5, 3)
     a = run(make_model(sd, "bf16x6"), img, ev)
@@ -129,6 +129,27 @@ def test_small_batches_run_on_the_fp32_kernels():
     got = run(make_model(sd5, "bf16x6", K=5), img16, ev16)
     for k in H.BIG_KEYS:
         assert np.abs(got[k] - ref[k].numpy()).max() <= H.TOL_BIG, k
+    assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref["logits"].numpy())).max() <= H.TOL_SIGMOID
+
+
+@pytest.mark.parametrize("B", [5, 6, 9, 20])
+def test_mid_size_batches_meet_the_fp32_gates_on_either_side_of_the_dispatch_rule(B):
+    """The split kernels take a micro-batch from 6 chunks on (72 workgroups of a 768-wide projection: the measured crossover,
+    tools/split_threshold_probe.py); B = 5 still runs on the fp32 kernels (bit-identical to compute="f32"), B = 6, 9, 20 on
+    partially filled split grids.  All against the CPU oracle at the fp32 gates."""
+    sd = synth.make_state_dict(4)
+    img, ev = synth.make_inputs(21, B)
+    got = run(make_model(sd, "bf16x6"), img, ev)
+    f32 = run(make_model(sd, "f32"), img, ev)
+    if B < 6:
+        for k in got:
+            assert np.array_equal(got[k], f32[k]), k
+    else:
+        assert not np.array_equal(got["logits"], f32["logits"])          # another arithmetic ran
+    ref = orc.forward(sd, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_layers=2, num_refinement_steps=10, nu=8))
+    for k in H.BIG_KEYS:
+        assert np.abs(got[k] - ref[k].numpy()).max() <= H.TOL_BIG, k
+    assert np.abs(got["logits"] - ref["logits"].numpy()).max() <= H.TOL_LOGIT
     assert np.abs(H.sigmoid(got["logits"]) - H.sigmoid(ref["logits"].numpy())).max() <= H.TOL_SIGMOID
 
 
