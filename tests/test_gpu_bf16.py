@@ -225,6 +225,31 @@ def test_inproj_row_block_kernel_equals_the_ring_kernel(monkeypatch, L, in_dtype
     assert bad[2] and bad[5] and bad.sum() == 2
 
 
+@pytest.mark.parametrize("B", [1, 3, 12, 20])
+def test_row_block_kernels_on_partially_filled_grids_equal_the_ring_kernels(monkeypatch, B):
+    """The row-block kernels take a projection from 128 workgroups on and the refinement chain from one chunk (4 blocks): B = 1, 3
+    run the chain beside ring-kernel projections, B = 12 adds the heads kernel, B = 20 all of them, on grids that fill a
+    fraction of the chip.  Against the same model with both thresholds out of reach (IEFVAD_ROWBLOCK_MIN_WGS,
+    IEFVAD_CHAIN_MIN_BLOCKS at model creation: ring kernels, 2K launches): every output bit for bit, the row means of the
+    fusion weights to fp32 rounding."""
+    sd = synth.make_state_dict(15, 768, 2, 4)
+    img, ev = synth.make_inputs(38, B)
+    ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+    kw = dict(outputs="full", graph_chunks=-1)
+    with torch.no_grad():
+        new = make_model(2, 4, 0.5, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+        monkeypatch.setenv("IEFVAD_ROWBLOCK_MIN_WGS", "1000000")
+        monkeypatch.setenv("IEFVAD_CHAIN_MIN_BLOCKS", "1000000")
+        old = make_model(2, 4, 0.5, "StudentT", 8, sd, **kw)(ti, te, None, None, None)
+    assert set(new) == set(old)
+    for k in new:
+        a, b = new[k].float(), old[k].float()
+        if k in ("w_i_mean", "w_e_mean"):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6), k
+        else:
+            assert torch.equal(a, b), (k, (a - b).abs().max().item())
+
+
 def test_refinement_chain_kernel_propagates_non_finite_rows(monkeypatch):
     """A NaN / inf in one snippet's fused state must stay in that row through the chain kernel exactly as through the
     projection launches (rows are independent in imf_vad.py:146-150)."""
