@@ -1665,7 +1665,7 @@ extern "C" int iefvad_gather_scores(iefvad_comm* c, const float* local, size_t c
 }
 
 // ------------------------------------------------------------------------------------------------
-// training-side loss head, forward only (csrc/loss.h)
+// training-side loss head: forward and the gradients with respect to the model's outputs (csrc/loss.h)
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T) {
     if (B <= 0 || T <= 0) return 0;
@@ -1699,6 +1699,37 @@ extern "C" int iefvad_loss_forward(const float* logits, const float* image_mu, c
     fa.inst = inst; fa.targets = targets; fa.part = part; fa.out = out; fa.B = B; fa.rows = rows; fa.lambda_reg = lambda_reg;
     fa.lambda_kl = lambda_kl;
     hipLaunchKernelGGL(iefvad_loss_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int iefvad_loss_backward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
+                                    const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
+                                    int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float grad_scale,
+                                    float* d_logits, float* d_image_mu, float* d_event_mu, float* d_image_logvar,
+                                    float* d_event_logvar, void* stream_) {
+    if (!logits || !lengths || !targets) return fail("iefvad_loss_backward: null argument");
+    const bool heads = d_image_mu || d_event_mu || d_image_logvar || d_event_logvar;
+    if (heads && !(image_mu && event_mu && image_logvar && event_logvar))
+        return fail("iefvad_loss_backward: image_mu, event_mu, image_logvar, event_logvar are needed for their gradients");
+    if (B <= 0) return fail("iefvad_loss_backward: B must be positive (got %d)", B);
+    if (T != IEF_T) return fail("iefvad_loss_backward: kernels are built for T = %d (got %d)", IEF_T, T);
+    if (noise_model != IEFVAD_NOISE_GAUSSIAN && noise_model != IEFVAD_NOISE_STUDENT_T)
+        return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");
+    if (noise_model == IEFVAD_NOISE_STUDENT_T && !(nu > 0.f)) return fail("iefvad_loss_backward: nu must be positive for StudentT");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (d_logits)
+        hipLaunchKernelGGL(iefvad_mil_topk_grad_kernel, dim3(B), dim3(256), 0, stream, logits, (const int*)lengths, targets, d_logits, T,
+                           grad_scale / (float)B);
+    if (heads) {
+        LossRowGradArgs ga;
+        ga.mu_i = image_mu; ga.mu_e = event_mu; ga.lv_i = image_logvar; ga.lv_e = event_logvar;
+        ga.d_mu_i = d_image_mu; ga.d_mu_e = d_event_mu; ga.d_lv_i = d_image_logvar; ga.d_lv_e = d_event_logvar;
+        ga.rows = B * T;
+        ga.lv_shift = noise_model == IEFVAD_NOISE_STUDENT_T ? logf(nu / (nu + 1.0f)) : 0.f;
+        ga.lambda_reg = lambda_reg; ga.lambda_kl = lambda_kl; ga.scale = grad_scale;
+        hipLaunchKernelGGL(iefvad_loss_rows_grad_kernel, dim3((ga.rows + 3) / 4), dim3(256), 0, stream, ga);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -9,7 +9,9 @@
 //   * the KL terms (ucf_train.py:84-98): -0.5 mean(1 + l - mu^2 - exp(l)) per modality, with l = logvar for the Gaussian
 //     noise model and logvar + log(nu / (nu + 1)) for Student-t.
 // No atomics: per-video and per-row partial results land in a workspace and ONE workgroup combines them in a fixed order,
-// so the losses are bit-reproducible from run to run.  The backward pass is not built.
+// so the losses are bit-reproducible from run to run.
+// Backward of the loss head (iefvad_loss_backward): the gradients of the total with respect to the five tensors above, i.e.
+// what autograd hands to the model's outputs; the model's own backward pass is not part of this library.
 #pragma once
 #include "common.h"
 
@@ -144,5 +146,110 @@ __global__ __launch_bounds__(256) void iefvad_loss_finish_kernel(LossFinishArgs 
         a.out[5] = (float)kli;
         a.out[6] = (float)kle;
         a.out[7] = (float)(cls + a.lambda_reg * (lcos + lnorm) + a.lambda_kl * (kli + kle));
+    }
+}
+
+// ---- backward of the loss head ------------------------------------------------------------------------------------------
+// d total / d logits: one workgroup per video.  p = top-k mean as in the forward; BCE'(p) as torch's binary_cross_entropy
+// backward evaluates it, (p - y) / max((1 - p) p, 1e-12); each of the k selected snippets gets sigma'(x) / k of it.
+__global__ __launch_bounds__(256) void iefvad_mil_topk_grad_kernel(const float* logits, const int* lengths, const float* targets,
+                                                                   float* d_logits, int T, float scale_over_B) {
+    __shared__ float s[LOSS_T];
+    __shared__ float w[4];
+    const int v = blockIdx.x, t = threadIdx.x;
+    int len = lengths[v];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const int k = len / 16 + 1;
+    const float x = (t < len) ? 1.0f / (1.0f + expf(-logits[(size_t)v * T + t])) : -1.0f;
+    s[t] = x;
+    __syncthreads();
+    int rank = 0;
+    for (int u = 0; u < T; ++u) {
+        const float y = s[u];
+        rank += (y > x) || (y == x && u < t);
+    }
+    const int kk = k < len ? k : len;
+    const bool sel = t < len && rank < kk;
+    float part = sel ? x : 0.f;
+    part = wave_sum(part);
+    if ((t & 63) == 0) w[t >> 6] = part;
+    __syncthreads();
+    const float p = kk > 0 ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)kk : 0.f;
+    const float y = targets[v];
+    const float dp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * scale_over_B;
+    d_logits[(size_t)v * T + t] = sel ? dp * (x * (1.0f - x)) / (float)kk : 0.f;
+}
+
+// d total / d (mu_i, mu_e, logvar_i, logvar_e): one wavefront per row.
+//   cosine term  (1/R) (1 - cos):  d/da = -(b^ - cos a^) / |a|   (a^ = a / |a|; F.normalize then F.cosine_similarity, clamps inactive)
+//   norm term    (1/R) ||a| - |b||: d/da = sign(|a| - |b|) a^
+//   KL           -0.5 / (R D) sum(1 + l - mu^2 - e^l): d/dmu = mu / (R D), d/dlogvar = -0.5 (1 - e^l) / (R D)
+struct LossRowGradArgs {
+    const float* mu_i; const float* mu_e; const float* lv_i; const float* lv_e;     // [rows, 768]
+    float* d_mu_i; float* d_mu_e; float* d_lv_i; float* d_lv_e;                     // [rows, 768], nullable each
+    int rows;
+    float lv_shift, lambda_reg, lambda_kl, scale;
+};
+__global__ __launch_bounds__(256) void iefvad_loss_rows_grad_kernel(LossRowGradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const size_t base = (size_t)row * IEF_D + 4 * lane;
+    f32x4 mi[3], me[3];
+    float sii = 0.f, see = 0.f, sie = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        mi[j] = *(const f32x4*)(a.mu_i + base + 256 * j);
+        me[j] = *(const f32x4*)(a.mu_e + base + 256 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sii += mi[j][e] * mi[j][e];
+            see += me[j][e] * me[j][e];
+            sie += mi[j][e] * me[j][e];
+        }
+    }
+    // F.normalize (x / max(|x|, 1e-12)) then F.cosine_similarity (each factor / max(its norm, 1e-8)), differentiated WITH their
+    // clamp branches, so that a zero row gets what autograd gives it (a 1e20-scale value: meaningless, but the same)
+    const float rni = sqrtf(wave_sum(sii)), rne = sqrtf(wave_sum(see));
+    const float ni = fmaxf(rni, 1e-12f), ne = fmaxf(rne, 1e-12f);
+    const float hi = rni / ni, he = rne / ne;                       // norms of the normalised rows: 1, or |x| 1e12 below the clamp
+    const float qi = fmaxf(hi, 1e-8f), qe = fmaxf(he, 1e-8f);
+    const float dh = wave_sum(sie) / (ni * ne);                     // u_i . u_e
+    const float cs = dh / (qi * qe);
+    const float al = 1.0f / (qi * qe);
+    const float bi = hi > 1e-8f ? cs / (hi * qi) : 0.f, be = he > 1e-8f ? cs / (he * qe) : 0.f;
+    // d cos / d a = c1 u_e + c2 u_i (u = normalised row), through the Jacobian of the normalisation
+    float c1i, c2i, c1e, c2e;
+    if (rni > 1e-12f) { c1i = al / rni; c2i = -(bi + al * dh - bi * hi * hi) / rni; } else { c1i = al * 1e12f; c2i = -bi * 1e12f; }
+    if (rne > 1e-12f) { c1e = al / rne; c2e = -(be + al * dh - be * he * he) / rne; } else { c1e = al * 1e12f; c2e = -be * 1e12f; }
+    const float invR = a.scale / (float)a.rows, invRD = invR / (float)IEF_D;
+    const float sg = rni > rne ? 1.f : (rni < rne ? -1.f : 0.f);
+    const float cr = a.lambda_reg * invR, ck = a.lambda_kl * invRD;
+    const float gni = rni > 0.f ? sg / rni : 0.f, gne = rne > 0.f ? -sg / rne : 0.f;      // d | |a| - |b| |: torch.norm's backward is 0 at 0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        f32x4 gi, ge;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ui = mi[j][e] / ni, ue = me[j][e] / ne;
+            gi[e] = cr * (-(c1i * ue + c2i * ui) + gni * mi[j][e]) + ck * mi[j][e];
+            ge[e] = cr * (-(c1e * ui + c2e * ue) + gne * me[j][e]) + ck * me[j][e];
+        }
+        if (a.d_mu_i) *(f32x4*)(a.d_mu_i + base + 256 * j) = gi;
+        if (a.d_mu_e) *(f32x4*)(a.d_mu_e + base + 256 * j) = ge;
+        if (a.d_lv_i) {
+            const f32x4 l = *(const f32x4*)(a.lv_i + base + 256 * j);
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = -0.5f * ck * (1.0f - expf(l[e] + a.lv_shift));
+            *(f32x4*)(a.d_lv_i + base + 256 * j) = g;
+        }
+        if (a.d_lv_e) {
+            const f32x4 l = *(const f32x4*)(a.lv_e + base + 256 * j);
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = -0.5f * ck * (1.0f - expf(l[e] + a.lv_shift));
+            *(f32x4*)(a.d_lv_e + base + 256 * j) = g;
+        }
     }
 }

@@ -1,13 +1,17 @@
-"""Training-side loss head, FORWARD ONLY: device counterparts of the reference's loss terms with the
-reference's call shapes, computed by libiefvad (`iefvad_loss_forward`, csrc/loss.h) -- no torch op computes anything here.
+"""Training-side loss head: device counterparts of the reference's loss terms with the reference's call
+shapes, computed by libiefvad (`iefvad_loss_forward` / `iefvad_loss_backward`, csrc/loss.h) -- no torch op computes anything here.
 
   * `CLAS2(logits, labels, lengths, device)`   -- /root/reference/train/loss.py:18-30
   * `training_losses(outputs, labels, lengths, ...)` -- the sum the trainers form, /root/reference/train/ucf_train.py:68-101
     (lambda_reg = lambda_kl = 1) and train/xd_train.py:60-75 (0.01, 0.01): classification + lambda_reg * (cosine + norm
     regulariser of image_mu / event_mu) + lambda_kl * (Gaussian or Student-t KL of both modalities).
 
-The values are exact forward results on tensors `iefvad_amd.MMFMIL` returns in eval mode; no graph is recorded: the backward
-pass, the optimiser and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this build.
+  * `training_loss(outputs, labels, lengths, ...)` -- the same total as ONE differentiable scalar: `.backward()` fills the
+    `.grad` of `logits`, `image_mu`, `event_mu`, `image_logvar`, `event_logvar` (the gradients `loss.backward()` hands to the
+    model's outputs in ucf_train.py:103), computed by `iefvad_loss_backward`.
+
+The model's own backward pass, the optimiser and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this
+build: the gradients stop at the tensors `iefvad_amd.MMFMIL` returns.
 """
 from __future__ import annotations
 
@@ -69,3 +73,59 @@ def training_losses(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, leng
     heads = (outputs["image_mu"], outputs["event_mu"], outputs["image_logvar"], outputs["event_logvar"])
     out = _run(outputs["logits"], heads, labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
     return {k: out[i] for i, k in enumerate(TERMS)}
+
+
+def _prep(logits, heads, labels, lengths):
+    dev = logits.device
+    B = int(logits.shape[0])
+    lg = logits.detach().reshape(B, -1).float().contiguous()
+    T = int(lg.shape[1])
+    targets = (1 - labels[:, 0].reshape(B)).to(device=dev, dtype=torch.float32).contiguous()
+    lens = torch.as_tensor(lengths).reshape(B).to(device=dev, dtype=torch.int32).contiguous()
+    hs = [t.detach().reshape(B * T, -1).float().contiguous() for t in heads]
+    return B, T, lg, targets, lens, hs
+
+
+class _LossHead(torch.autograd.Function):
+    """total = classification + lambda_reg * reg + lambda_kl * kl as one differentiable node (both passes in libiefvad)."""
+
+    @staticmethod
+    def forward(ctx, logits, image_mu, event_mu, image_logvar, event_logvar, labels, lengths, noise_model, nu, lambda_reg, lambda_kl):
+        heads = (image_mu, event_mu, image_logvar, event_logvar)
+        out = _run(logits.detach(), tuple(t.detach() for t in heads), labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
+        ctx.save_for_backward(logits, image_mu, event_mu, image_logvar, event_logvar, labels)
+        ctx.meta = (lengths, noise_model, float(nu), float(lambda_reg), float(lambda_kl))
+        return out[7].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        logits, image_mu, event_mu, image_logvar, event_logvar, labels = ctx.saved_tensors
+        lengths, noise_model, nu, lambda_reg, lambda_kl = ctx.meta
+        heads = (image_mu, event_mu, image_logvar, event_logvar)
+        B, T, lg, targets, lens, hs = _prep(logits, heads, labels, lengths)
+        dev = logits.device
+        need = list(ctx.needs_input_grad[:5])
+        grads = [torch.empty_like(lg) if need[0] else None] + [torch.empty_like(hs[i]) if need[1 + i] else None for i in range(4)]
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        lib = _lib.load_library()
+        with torch.cuda.device(dev):
+            rc = lib.iefvad_loss_backward(ptr(lg), ptr(hs[0]), ptr(hs[1]), ptr(hs[2]), ptr(hs[3]), ptr(lens), ptr(targets), B, T,
+                                          _lib.NOISE_STUDENT_T if noise_model == "StudentT" else _lib.NOISE_GAUSSIAN, nu, lambda_reg,
+                                          lambda_kl, float(grad_out), ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]),
+                                          ptr(grads[4]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("iefvad_loss_backward: " + _lib.last_error())
+        shaped = [g.reshape(x.shape).to(x.dtype) if g is not None else None
+                  for g, x in zip(grads, (logits, image_mu, event_mu, image_logvar, event_logvar))]
+        return (*shaped, None, None, None, None, None, None)
+
+
+def training_loss(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, lengths, noise_model: str = "StudentT", nu: float = 8,
+                  lambda_reg: float = 1.0, lambda_kl: float = 1.0) -> torch.Tensor:
+    """The trainers' total loss (ucf_train.py:100-102) as a differentiable 0-dim device tensor; see the module docstring."""
+    if noise_model not in ("Gaussian", "StudentT"):
+        raise ValueError("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.")
+    if not outputs["logits"].is_cuda:
+        raise RuntimeError("iefvad_amd.losses runs on a HIP device only; there is no CPU fallback")
+    return _LossHead.apply(outputs["logits"], outputs["image_mu"], outputs["event_mu"], outputs["image_logvar"], outputs["event_logvar"],
+                           labels, lengths, noise_model, nu, lambda_reg, lambda_kl)

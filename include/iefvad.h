@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 3
+#define IEFVAD_ABI_VERSION 4
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -181,7 +181,7 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
                           const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
                           size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
 
-/* ---- training-side loss head, FORWARD ONLY ---------------------------------------------------------
+/* ---- training-side loss head: forward, and its gradients w.r.t. the model's outputs -----------------
  * The three terms the reference's trainers add up (/root/reference/train/ucf_train.py:68-101, train/xd_train.py:60-75), as
  * device reductions over tensors iefvad_forward already produces:
  *   out[0] classification  CLAS2(logits, labels, lengths) (/root/reference/train/loss.py:18-30): per video the mean of the
@@ -193,12 +193,21 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
  * logits [B, T]; the four 768-d tensors [B*T, 768]; lengths int32 [B] and targets fp32 [B] (1 = abnormal, i.e.
  * 1 - labels[:, 0], loss.py:20) on the DEVICE; out: 8 fp32 on the device.  T must be 256.  Deterministic (no atomics).
  * The four 768-d pointers may all be NULL: then only out[0] (and out[7] = out[0]) is computed -- CLAS2 alone.
- * The backward pass and the optimiser step are not part of this library. */
+ * iefvad_loss_backward: the gradients of grad_scale * total with respect to logits [B, T] and the four 768-d tensors (what
+ * `loss.backward()` hands to the model's outputs in /root/reference/train/ucf_train.py:103): CLAS2 through torch's BCE
+ * backward ((p - y) / max((1 - p) p, 1e-12)) and the top-k selection, the cosine / norm regulariser, the KL terms.  Each
+ * d_* pointer may be NULL (that gradient is not written).  The model's own backward pass and the optimiser step are not part
+ * of this library. */
 size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T);
 int iefvad_loss_forward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
                         const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
                         int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float* out, void* workspace,
                         size_t workspace_bytes, void* stream);
+int iefvad_loss_backward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
+                         const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
+                         int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float grad_scale,
+                         float* d_logits, float* d_image_mu, float* d_event_mu, float* d_image_logvar,
+                         float* d_event_logvar, void* stream);
 
 /* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
  * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a

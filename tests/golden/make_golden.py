@@ -283,7 +283,60 @@ def gen_loss_case():
     print("wrote", path, store["seed1"])
 
 
+def gen_loss_grad_case():
+    """f-4, backward of the loss head: autograd through the reference's own CLAS2 (/root/reference/train/loss.py:18-30) and the
+    trainers' torch calls (train/ucf_train.py:75-101) on the seeded stand-ins of gen_loss_case, evaluated in fp64.  Stored: 2048
+    sampled gradient entries per tensor (seeded indices; for d logits only from videos without tied scores -- with ties
+    torch.topk's choice among equals decides who gets the gradient), the per-video sums of d logits (tie-invariant), the whole
+    gradient row of the all-zero image_mu row (the clamp branches of F.normalize / F.cosine_similarity) and the abs-sums."""
+    import math
+    import torch.nn.functional as F
+    sys.path.insert(0, REF)
+    from train.loss import CLAS2
+    store = {}
+    for seed, noise, nu, lam_reg, lam_kl in ((1, "StudentT", 8, 1.0, 1.0), (2, "Gaussian", 8, 0.01, 0.01)):
+        o, labels, lengths = synth.make_loss_inputs(seed)
+        t = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in o.items()}
+        cls = CLAS2(t["logits"], torch.from_numpy(labels).double(), torch.from_numpy(lengths), "cpu")
+        image_mu, event_mu = t["image_mu"], t["event_mu"]
+        cos_sim = F.cosine_similarity(F.normalize(image_mu, p=2, dim=-1), F.normalize(event_mu, p=2, dim=-1), dim=-1)   # :75-77
+        loss_cos = (1 - cos_sim).mean()
+        loss_norm = torch.abs(torch.norm(image_mu, p=2, dim=-1) - torch.norm(event_mu, p=2, dim=-1)).mean()
+        sh = math.log(nu / (nu + 1)) if noise == "StudentT" else 0.0
+        kl = 0.0
+        for mu, lv in ((image_mu, t["image_logvar"]), (event_mu, t["event_logvar"])):
+            e = lv + sh
+            kl = kl + (-0.5 * torch.mean(1 + e - mu.pow(2) - e.exp()))
+        total = cls + lam_reg * (loss_cos + loss_norm) + lam_kl * kl                                                   # :100-102
+        total.backward()
+        rng = np.random.default_rng([seed, 77])
+        tag = f"seed{seed}"
+        store[tag + "_cfg"] = np.array([nu, lam_reg, lam_kl, 1.0 if noise == "StudentT" else 0.0])
+        store[tag + "_total"] = np.array(float(total))
+        for k in ("logits", "image_mu", "event_mu", "image_logvar", "event_logvar"):
+            g = t[k].grad.numpy().reshape(-1)
+            if k == "logits":
+                B, T = t[k].shape[0], t[k].shape[1]
+                ok = [v for v in range(B) if v not in (0, 2)]                  # videos 0 and 2 hold exactly tied scores
+                idx = np.concatenate([v * T + rng.choice(T, 256, replace=False) for v in ok])
+                store[tag + "_logits_video_sums"] = t[k].grad.numpy().reshape(B, T).sum(1)
+            else:
+                idx = rng.choice(g.size, 2048, replace=False)
+                idx = idx[(idx // 768) != (1 * 256 + 5)]                       # the zero row is stored whole below
+            store[tag + "_" + k + "_idx"] = idx.astype(np.int64)
+            store[tag + "_" + k + "_val"] = g[idx]
+            store[tag + "_" + k + "_abssum"] = np.array(np.abs(g[np.isfinite(g)]).sum())
+        store[tag + "_image_mu_zero_row"] = t["image_mu"].grad.numpy()[1, 5]
+        store[tag + "_event_mu_zero_row"] = t["event_mu"].grad.numpy()[1, 5]
+    path = os.path.join(HERE, "loss_grads.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes;", float(store["seed1_total"]), np.abs(store["seed1_image_mu_zero_row"]).max())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lossgrad":
+        gen_loss_grad_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss":
         gen_loss_case()
         sys.exit(0)
@@ -307,3 +360,4 @@ if __name__ == "__main__":
     gen_sweep_case()
     gen_config5_gt()
     gen_loss_case()
+    gen_loss_grad_case()

@@ -103,3 +103,18 @@ def test_oracle_loss_terms_match_the_reference_fixture(golden_dir):
             got = [t["classification"], t["cos"], t["norm"], t["kl_image"], t["kl_event"]]
             ref = [want[0], want[1], want[2], want[3 + 2 * j], want[4 + 2 * j]]
             assert np.allclose(got, ref, rtol=0, atol=2e-6), (seed, noise, nu, got, ref)
+
+
+def test_loss_gradient_fixture_is_consistent_with_the_loss_fixture(golden_dir):
+    """loss_grads.npz (autograd through the reference's CLAS2 + the trainers' torch calls) was generated from the same inputs as
+    loss_terms.npz: its totals must be the sums of that fixture's terms, and its tie-invariant sums must balance."""
+    import os
+    terms = np.load(os.path.join(golden_dir, "loss_terms.npz"))
+    grads = np.load(os.path.join(golden_dir, "loss_grads.npz"))
+    for seed, j in ((1, 1), (2, 0)):                       # seed 1: StudentT nu = 8 (1, 1); seed 2: Gaussian (0.01, 0.01)
+        t = terms[f"seed{seed}"]
+        nu, lam_reg, lam_kl, student = grads[f"seed{seed}_cfg"]
+        want = t[0] + lam_reg * (t[1] + t[2]) + lam_kl * (t[3 + 2 * j] + t[4 + 2 * j])
+        assert abs(float(grads[f"seed{seed}_total"]) - want) <= 1e-6 * max(1.0, abs(want))      # fp32 terms there, fp64 here
+        assert np.isfinite(grads[f"seed{seed}_logits_video_sums"]).all()
+        assert np.abs(grads[f"seed{seed}_image_mu_zero_row"]).max() > 1e12          # the clamp branch of F.normalize
