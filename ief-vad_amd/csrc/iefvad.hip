@@ -1734,6 +1734,22 @@ extern "C" int iefvad_loss_backward(const float* logits, const float* image_mu, 
     return 0;
 }
 
+extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int32_t step, void* stream_) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail("iefvad_adamw_step: null argument");
+    if (step < 1) return fail("iefvad_adamw_step: step counts from 1 (got %d)", step);
+    if (n == 0) return 0;
+    AdamWArgs a;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(iefvad_adamw_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of the whole-video path: gather the videos' rows into one (pinned) staging buffer
 // ------------------------------------------------------------------------------------------------

@@ -253,3 +253,27 @@ __global__ __launch_bounds__(256) void iefvad_loss_rows_grad_kernel(LossRowGradA
         }
     }
 }
+
+// ---- optimiser step: torch.optim.AdamW as the trainers construct it (/root/reference/train/ucf_train.py:28, xd_train.py:25:
+// lr from the arguments, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01, no amsgrad), single-tensor form, torch's operation order:
+//   p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+// bc1 = 1 - b1^t and sqrt(bc2) = sqrt(1 - b2^t) come from the host (torch computes them in Python floats).
+struct AdamWArgs {
+    float* p; const float* g; float* m; float* v;
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+};
+__global__ __launch_bounds__(256) void iefvad_adamw_kernel(AdamWArgs a) {
+    const float step_size = a.lr / a.bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = a.g[i];
+        float p = a.p[i];
+        p = p * (1.0f - a.lr * a.weight_decay);
+        const float m = a.m[i] + (1.0f - a.beta1) * (g - a.m[i]);                  // lerp_(grad, 1 - beta1)
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * (g * g);            // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        a.m[i] = m;
+        a.v[i] = v;
+        a.p[i] = p - step_size * (m / denom);                                      // addcdiv_(exp_avg, denom, value = -step_size)
+    }
+}

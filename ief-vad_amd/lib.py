@@ -26,7 +26,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_last_error",
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
-           "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward",
+           "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
            "iefvad_loss_workspace_bytes"]
 COMM_ID_BYTES = 128
 
@@ -115,6 +115,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_loss_forward.restype = C.c_int
     lib.iefvad_loss_backward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 6
     lib.iefvad_loss_backward.restype = C.c_int
+    lib.iefvad_adamw_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 5 + [C.c_int32, C.c_void_p]
+    lib.iefvad_adamw_step.restype = C.c_int
     lib.iefvad_host_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]
     lib.iefvad_host_gather.restype = C.c_int
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

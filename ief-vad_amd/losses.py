@@ -10,8 +10,10 @@ shapes, computed by libiefvad (`iefvad_loss_forward` / `iefvad_loss_backward`, c
     `.grad` of `logits`, `image_mu`, `event_mu`, `image_logvar`, `event_logvar` (the gradients `loss.backward()` hands to the
     model's outputs in ucf_train.py:103), computed by `iefvad_loss_backward`.
 
-The model's own backward pass, the optimiser and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this
-build: the gradients stop at the tensors `iefvad_amd.MMFMIL` returns.
+  * `AdamW(params, lr)` -- torch.optim.AdamW's update as the trainers construct it (ucf_train.py:28), `iefvad_adamw_step`.
+
+The model's own backward pass and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this build: the
+gradients stop at the tensors `iefvad_amd.MMFMIL` returns.
 """
 from __future__ import annotations
 
@@ -129,3 +131,36 @@ def training_loss(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, length
         raise RuntimeError("iefvad_amd.losses runs on a HIP device only; there is no CPU fallback")
     return _LossHead.apply(outputs["logits"], outputs["image_mu"], outputs["event_mu"], outputs["image_logvar"], outputs["event_logvar"],
                            labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
+
+
+class AdamW:
+    """torch.optim.AdamW's update (the optimiser of /root/reference/train/ucf_train.py:28, xd_train.py:25) on device tensors,
+    one `iefvad_adamw_step` launch per tensor: `AdamW(params, lr)`, `.step()` reads each parameter's `.grad`, `.zero_grad()`.
+    State (`exp_avg`, `exp_avg_sq`, the per-parameter step counts) lives here; amsgrad, maximize and parameter groups are not offered."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        self.params = [p for p in params]
+        if any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
+            raise ValueError("AdamW: contiguous fp32 tensors on a HIP device only; there is no CPU fallback")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in self.params]
+        self.steps = [0] * len(self.params)          # per parameter, as torch counts them: only steps that saw a gradient
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load_library()
+        for i, (p, (m, v)) in enumerate(zip(self.params, self.state)):
+            if p.grad is None:
+                continue
+            self.steps[i] += 1
+            g = p.grad.contiguous().float()
+            with torch.cuda.device(p.device):
+                rc = lib.iefvad_adamw_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                           C.c_void_p(v.data_ptr()), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                           self.weight_decay, self.steps[i], C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("iefvad_adamw_step: " + _lib.last_error())

@@ -196,8 +196,7 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
  * iefvad_loss_backward: the gradients of grad_scale * total with respect to logits [B, T] and the four 768-d tensors (what
  * `loss.backward()` hands to the model's outputs in /root/reference/train/ucf_train.py:103): CLAS2 through torch's BCE
  * backward ((p - y) / max((1 - p) p, 1e-12)) and the top-k selection, the cosine / norm regulariser, the KL terms.  Each
- * d_* pointer may be NULL (that gradient is not written).  The model's own backward pass and the optimiser step are not part
- * of this library. */
+ * d_* pointer may be NULL (that gradient is not written).  The model's own backward pass is not part of this library. */
 size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T);
 int iefvad_loss_forward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
                         const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
@@ -208,6 +207,12 @@ int iefvad_loss_backward(const float* logits, const float* image_mu, const float
                          int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float grad_scale,
                          float* d_logits, float* d_image_mu, float* d_event_mu, float* d_image_logvar,
                          float* d_event_logvar, void* stream);
+
+/* One torch.optim.AdamW step (as /root/reference/train/ucf_train.py:28 constructs it: betas (0.9, 0.999), eps 1e-8, weight_decay
+ * 0.01, amsgrad off) on one flat fp32 tensor, in place, in torch's operation order; `step` counts from 1 (bias corrections are
+ * taken on the host in double, as torch takes them in Python floats).  All pointers are device pointers of n floats. */
+int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
  * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a

@@ -145,3 +145,28 @@ def test_loss_gradient_is_the_directional_derivative_of_the_oracle_total():
     y["logits"].requires_grad_(True)
     losses.training_loss(y, labels, lengths).backward()
     assert y["logits"].grad is not None and y["image_mu"].grad is None
+
+
+def test_adamw_step_matches_torch_optim_adamw():
+    """`losses.AdamW` (iefvad_adamw_step) against torch.optim.AdamW on the CPU, constructed as the trainers construct it
+    (`AdamW(params, lr=...)`: betas (0.9, 0.999), eps 1e-8, weight_decay 0.01), six steps on two tensors with fresh gradients
+    each step; a parameter without a gradient is left alone."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(768, 768), (2304,), (5,)]
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    dev = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.AdamW(ref, lr=3e-4)
+    o_dev = losses.AdamW(dev, lr=3e-4)
+    for step in range(6):
+        for i, (r, d) in enumerate(zip(ref, dev)):
+            if i == 2 and step % 2:
+                r.grad, d.grad = None, None
+                continue
+            gr = torch.randn(r.shape, generator=g) * (10.0 ** (step - 3))
+            r.grad, d.grad = gr.clone(), gr.clone().cuda()
+        o_ref.step()
+        o_dev.step()
+        for r, d in zip(ref, dev):
+            assert float((r.detach() - d.detach().cpu()).abs().max()) <= 2e-6 * float(r.detach().abs().max()), step
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        losses.AdamW([torch.zeros(4)])
