@@ -55,7 +55,7 @@ GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
-PROFILE_ROUND = "r03"                                           # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in
+PROFILE_ROUNDS = ("r04", "r03")                                 # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in, newest first
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
                "bf16": "iefvad_inproj_chain_f32in_kernel / iefvad_inproj_chain_bf16_kernel (in_proj; the first layer rounds the fp32 "
                        "rows to bf16 itself) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + scorer, one launch) + "
@@ -190,26 +190,29 @@ def roofline_block(compute, stage, steps, rows_per_step):
 
 
 def traffic_from_profiles(compute, rows_per_launch):
-    """HBM-side bytes per GEMM launch.  NOT measured in this run: PMC counters need their own rocprofv3 passes, so the figure
-    is read from the committed summary of such passes under profiles/ (tools/hbm_traffic.py writes it) -- and only from this
-    round's file, at this launch size, whose recorded kernel list matches the kernels this build dispatches; otherwise null.
-    Returned as an object that names its source."""
+    """HBM-side bytes per GEMM launch as scalar keys of the roofline block.  NOT measured in this run: PMC counters need their
+    own rocprofv3 passes, so `traffic` is read from the committed summary of such passes under profiles/ (tools/hbm_traffic.py
+    writes it) -- and only from this round's file, at this launch size, whose recorded kernel list matches the kernels this build
+    dispatches; otherwise it is null.  Provenance rides in sibling scalars (`traffic_source`, `traffic_head`, ...)."""
+    none = {"traffic": None, "traffic_measured_in_this_run": False}
     name = {"f32": "gemm_hbm_traffic.json", "bf16x6": "gemm_split_hbm_traffic.json", "bf16": "gemm_bf16_hbm_traffic.json"}.get(compute)
     if not name:
-        return None
-    rel = os.path.join("profiles", f"{PROFILE_ROUND}_{name}")
-    path = os.path.join(ROOT, rel)
-    if not os.path.exists(path):
-        return None
-    tj = json.load(open(path))
-    if tj.get("rows_per_launch") != rows_per_launch:
-        return None
-    kernels = tj.get("kernels") or ([tj["kernel"]] if "kernel" in tj else [])
-    if kernels and not all(k in GEMM_KERNEL[compute] for k in kernels):
-        return None                                  # a PMC figure of another kernel set must not sit beside fresh timings
-    return {"bytes_per_launch": tj["traffic_bytes_per_launch"], "source": rel, "measured_in_this_run": False,
-            "collected_at_head": tj.get("head"), "kernels": kernels,
-            "over_algorithmic": tj.get("traffic_over_algorithmic")}
+        return none
+    for rnd in PROFILE_ROUNDS:                           # newest first
+        rel = os.path.join("profiles", f"{rnd}_{name}")
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        if tj.get("rows_per_launch") != rows_per_launch:
+            continue
+        kernels = tj.get("kernels") or ([tj["kernel"]] if "kernel" in tj else [])
+        if kernels and not all(k in GEMM_KERNEL[compute] for k in kernels):
+            continue                                     # a PMC figure of another kernel set must not sit beside fresh timings
+        return {"traffic": float(tj["traffic_bytes_per_launch"]), "traffic_unit": "bytes per launch (fabric FETCH_SIZE + WRITE_SIZE)",
+                "traffic_source": rel, "traffic_head": tj.get("head"), "traffic_measured_in_this_run": False,
+                "traffic_over_algorithmic": tj.get("traffic_over_algorithmic"), "traffic_kernels": ", ".join(kernels)}
+    return none
 
 
 def run_mode(model, img, ev, steps, warmup=1):
@@ -238,7 +241,7 @@ def extra_mode(sd, margs, dev, img, ev, a, compute, steps=3):
     value = B * T * steps / dt
     roof = roofline_block(compute, stage, steps, B * T)
     mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if compute == "f32" else 1024)           # library defaults
-    roof["traffic"] = traffic_from_profiles(compute, min(B, mb_eff) * T)
+    roof.update(traffic_from_profiles(compute, min(B, mb_eff) * T))
     out = {"compute": compute, "dtype": DTYPE[compute], "value": value, "unit": "snippets/s", "steps": steps,
            "ms_per_step": dt / steps * 1e3, "roofline": roof,
            "end_to_end_tflops": TOTAL_FLOPS_PER_SNIPPET * value / 1e12,
@@ -572,7 +575,7 @@ def main():
         if gpu:
             roof = roofline_block(a.compute, stage, a.steps, B * T)
             mb_eff = a.micro_batch if a.micro_batch > 0 else (256 if a.compute == "f32" else 1024)     # library defaults
-            roof["traffic"] = traffic_from_profiles(a.compute, min(B, mb_eff) * T)
+            roof.update(traffic_from_profiles(a.compute, min(B, mb_eff) * T))
             line["roofline"] = roof
             line["stage_ms_per_step"] = {k: v / a.steps for k, v in stage.items() if k.endswith("_ms")}
             line["end_to_end_tflops_per_gpu"] = TOTAL_FLOPS_PER_SNIPPET * value / world / 1e12

@@ -763,11 +763,10 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 }
             }
             hipEvent_t e = tm.begin(ST_CAST);
+            // (the NaN flags of ALL the call's videos are already set: forward_videos_impl scans every pass's chunks before the
+            // first pass runs, because test.py:90-95 decides per whole video and a video may straddle passes)
 #define RAGGED_IN(T)                                                                                                        \
     do {                                                                                                                    \
-        if (rg->d_flags)                                                                                                    \
-            hipLaunchKernelGGL(iefvad_nanflag_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,          \
-                               (const T*)rg->ev_rows, rg->d_chunks, (int*)rg->d_flags);                                     \
         hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,         \
                            (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], need_xb0 ? xb[0] : (bf16_t*)nullptr, \
                            need_xb0 ? xb[1] : (bf16_t*)nullptr, enc_rows_mode ? 0 : IEF_T);                                  \
@@ -1306,6 +1305,27 @@ static int forward_videos_impl(iefvad_handle* h, const void* img_rows, const voi
     const size_t esz = in_elem_bytes(in_dtype);
     long long row0 = 0;
     int rc = 0;
+    if (dflags) {
+        // The conditional nan_to_num of test.py:90-95 is decided on the WHOLE video tensor, and a video may straddle micro-batch
+        // passes: every chunk of the call is scanned before the first pass lays out (and fixes up) its rows.  src_row is
+        // pass-relative, so the scan goes pass by pass too, with the pass's base pointers.
+        hipEvent_t e = tm.begin(ST_CAST);
+        long long r0 = 0;
+        for (long long c0 = 0; c0 < total_chunks; c0 += mb) {
+            const int nb = (int)((total_chunks - c0 < mb) ? (total_chunks - c0) : mb);
+            const void* pi = (const char*)img_rows + (size_t)r0 * IEF_D * esz;
+            const void* pe = (const char*)ev_rows + (size_t)r0 * IEF_D * esz;
+            if (in_dtype == IEFVAD_IN_F32)
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<float>, dim3(nb, 2), dim3(256), 0, stream, (const float*)pi, (const float*)pe, dc + c0, (int*)dflags);
+            else if (in_dtype == IEFVAD_IN_F16)
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<__half>, dim3(nb, 2), dim3(256), 0, stream, (const __half*)pi, (const __half*)pe, dc + c0, (int*)dflags);
+            else
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<__hip_bfloat16>, dim3(nb, 2), dim3(256), 0, stream, (const __hip_bfloat16*)pi, (const __hip_bfloat16*)pe, dc + c0, (int*)dflags);
+            for (int j = 0; j < nb; ++j) r0 += hc[c0 + j].valid;
+        }
+        tm.end(e);
+        HIP_TRY(hipGetLastError());
+    }
     for (long long c0 = 0; c0 < total_chunks && !rc; c0 += mb) {
         const int nb = (int)((total_chunks - c0 < mb) ? (total_chunks - c0) : mb);
         long long vrows = 0;

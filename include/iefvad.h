@@ -164,7 +164,9 @@ int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int3
  * for a batch of videos with only the VALID rows crossing the boundary:
  *   img_rows, ev_rows   device, [sum(lengths), D] of `in_dtype`: the videos' feature rows concatenated in list order (no padding)
  *   lengths             HOST array of nvideos snippet counts (>= 1)
- *   nan_to_num          non-zero: the conditional replacement above, decided per video and per modality on the device
+ *   nan_to_num          non-zero: the conditional replacement above, decided per WHOLE video and per modality on the device: every
+ *                       chunk of the call is scanned before the first micro-batch pass lays out its rows, so a video that
+ *                       straddles passes is treated as the reference treats its one tensor
  *                       (NaN -> 0, +-inf -> the largest / smallest finite value of `in_dtype`); zero: rows are used as they are
  *   logits, w_i_mean, w_e_mean   device, [sum(lengths)] fp32 each, the means nullable: per-snippet results in the same order
  * Chunks are laid out on the device (zero padded; the all-zero chunk that process_split appends to a len % 256 == 0 video,

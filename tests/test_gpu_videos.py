@@ -150,6 +150,46 @@ def test_forward_videos_nan_rule_matches_the_host_rule(dtype):
     assert np.isnan(lg[off[1]:off[2]]).all() and np.isfinite(lg[off[0]:off[1]]).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("micro_batch", [2, 3])
+def test_nan_rule_is_decided_per_video_across_micro_batch_passes(dtype, micro_batch):
+    """test.py:90-95 looks at the WHOLE video tensor.  Video 1 (6 chunks) holds -inf in chunk 0 and +inf in chunk 1 and its only
+    NaN in chunk 3; with micro_batch = 2 / 3 those chunks are in different passes of the call, so the flag must be known before
+    the first pass lays its rows out.  The reference replaces the infs (fp16: +-65504 -> finite scores everywhere; fp32: 3.4e38
+    overflows inside in_proj, NaN chunk in the reference too).  Video 2 has an inf in its event features and no NaN: left alone.
+    Compared with the host rule (`harness._unpack_item`: torch.isnan(x).any() / torch.nan_to_num on the padded tensor) followed
+    by the dense forward -- bit for bit including the NaN pattern."""
+    lengths = [40, 1400, 300, 256]
+    vids = videos(lengths, seed=21, dtype=dtype)
+    vids[1][0][3, 9] = -np.inf          # chunk 0
+    vids[1][0][300, 100] = np.inf       # chunk 1
+    vids[1][0][800, 5] = np.nan         # chunk 3: a later pass
+    vids[2][1][10, 10] = np.inf         # no NaN in this video: stays inf
+    model, _ = make_model("f32", outputs="scores", micro_batch=micro_batch)
+    fixed = []
+    for i, (img, ev) in enumerate(vids):
+        ci, n = harness.process_split(img, 256)
+        ce, _ = harness.process_split(ev, 256)
+        item = (torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n]))
+        a, b, _, _ = harness._unpack_item(item, 256, "ucfcrime", None)
+        fixed.append((a.reshape(-1, 768)[:n].numpy().copy(), b.reshape(-1, 768)[:n].numpy().copy()))
+    assert np.isfinite(fixed[1][0].astype(np.float64)).all() and np.isinf(fixed[2][1]).any()
+    want = dense_reference(model, fixed)
+    got = ragged(model, vids)
+    for k in want:
+        a, b = want[k].cpu().numpy(), got[k].cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0)), k
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    lg = got["logits"].cpu().numpy()
+    if dtype == np.float16:
+        assert np.isfinite(lg[off[1]:off[2]]).all()                # the reference's fp16 answer: +-65504, finite scores
+    else:
+        assert np.isnan(lg[off[1]:off[1] + 512]).all() and np.isfinite(lg[off[1] + 512:off[2]]).all()
+    assert np.isnan(lg[off[2]:off[2] + 256]).all() and np.isfinite(lg[off[2] + 256:off[3]]).all()
+    assert np.isfinite(lg[off[0]:off[1]]).all() and np.isfinite(lg[off[3]:]).all()
+
+
 def test_forward_videos_matches_the_oracle_and_rejects_bad_arguments():
     model, sd = make_model("f32", outputs="scores")
     vids = videos([90, 257, 30], seed=10)
