@@ -31,6 +31,7 @@
 #include "heads_chain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
+#include "backward.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -117,6 +118,7 @@ struct iefvad_handle {
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
     struct MetaRing* meta;      // pinned / device metadata buffers of iefvad_forward_videos
+    struct TrainState* train;   // records of the train-mode forwards whose backward is outstanding (train.h)
 };
 static const int kAmaxActBase = 256;   // running-max slots of the projection matrices (multi-way words); behind them the activations'
 static int amax_act_tensors(int L, int K) { return 2 + 6 * L + 2 * K + 1; }   // inputs, per layer att|x|qkv x 2 modalities, z_0..z_K, h_0..h_{K-1}
@@ -235,6 +237,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
 static void release_events(iefvad_handle* h);
 static void release_graphs(iefvad_handle* h);
 static void release_meta(iefvad_handle* h);
+static void release_train(iefvad_handle* h);
 
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
@@ -253,6 +256,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     release_events(h);
     release_graphs(h);
     release_meta(h);
+    release_train(h);
     delete h;
 }
 
@@ -1556,6 +1560,11 @@ extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const voi
 
 
 // ------------------------------------------------------------------------------------------------
+// training: train-mode forward and the model's backward pass
+// ------------------------------------------------------------------------------------------------
+#include "train.h"
+
+// ------------------------------------------------------------------------------------------------
 // multi-GPU score gather (include/iefvad.h; csrc/gather.h binds librccl at run time)
 // ------------------------------------------------------------------------------------------------
 #define RCCL_TRY(api, expr)                                                                                   \
@@ -1727,7 +1736,7 @@ extern "C" int iefvad_loss_backward(const float* logits, const float* image_mu, 
                                     const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
                                     int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float grad_scale,
                                     float* d_logits, float* d_image_mu, float* d_event_mu, float* d_image_logvar,
-                                    float* d_event_logvar, void* stream_) {
+                                    float* d_event_logvar, const float* grad_scale_dev, void* stream_) {
     if (!logits || !lengths || !targets) return fail("iefvad_loss_backward: null argument");
     const bool heads = d_image_mu || d_event_mu || d_image_logvar || d_event_logvar;
     if (heads && !(image_mu && event_mu && image_logvar && event_logvar))
@@ -1740,30 +1749,35 @@ extern "C" int iefvad_loss_backward(const float* logits, const float* image_mu, 
     hipStream_t stream = (hipStream_t)stream_;
     if (d_logits)
         hipLaunchKernelGGL(iefvad_mil_topk_grad_kernel, dim3(B), dim3(256), 0, stream, logits, (const int*)lengths, targets, d_logits, T,
-                           grad_scale / (float)B);
+                           grad_scale / (float)B, grad_scale_dev);
     if (heads) {
         LossRowGradArgs ga;
         ga.mu_i = image_mu; ga.mu_e = event_mu; ga.lv_i = image_logvar; ga.lv_e = event_logvar;
         ga.d_mu_i = d_image_mu; ga.d_mu_e = d_event_mu; ga.d_lv_i = d_image_logvar; ga.d_lv_e = d_event_logvar;
         ga.rows = B * T;
         ga.lv_shift = noise_model == IEFVAD_NOISE_STUDENT_T ? logf(nu / (nu + 1.0f)) : 0.f;
-        ga.lambda_reg = lambda_reg; ga.lambda_kl = lambda_kl; ga.scale = grad_scale;
+        ga.lambda_reg = lambda_reg; ga.lambda_kl = lambda_kl; ga.scale = grad_scale; ga.scale_dev = grad_scale_dev;
         hipLaunchKernelGGL(iefvad_loss_rows_grad_kernel, dim3((ga.rows + 3) / 4), dim3(256), 0, stream, ga);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, int32_t step, void* stream_) {
+extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                                 double beta2, double eps, double weight_decay, int32_t step, void* stream_) {
     if (!param || !grad || !exp_avg || !exp_avg_sq) return fail("iefvad_adamw_step: null argument");
     if (step < 1) return fail("iefvad_adamw_step: step counts from 1 (got %d)", step);
     if (n == 0) return 0;
     AdamWArgs a;
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    // torch forms these in Python floats (doubles) and rounds once when they meet the fp32 tensors
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.w1 = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.eps = (float)eps;
     const size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(iefvad_adamw_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());

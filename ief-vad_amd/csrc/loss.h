@@ -18,28 +18,32 @@
 #define LOSS_T IEF_T
 
 // one workgroup (256 threads = the T snippets) per video: top-k mean of the sigmoid scores over the valid prefix
+// rank order of torch.topk(largest=True): NaN counts as larger than every number; equal keys are ordered by index (any choice among
+// equal VALUES gives the same mean; among NaNs the mean is NaN anyway)
+__device__ __forceinline__ bool topk_before(float y, int u, float x, int t) {
+    const bool ny = y != y, nx = x != x;
+    if (ny || nx) return ny && (!nx || u < t);
+    return (y > x) || (y == x && u < t);
+}
+
 __global__ __launch_bounds__(256) void iefvad_mil_topk_kernel(const float* logits, const int* lengths, float* inst, int T) {
     __shared__ float s[LOSS_T];
     const int v = blockIdx.x, t = threadIdx.x;
-    int len = lengths[v];
-    len = len < 0 ? 0 : (len > T ? T : len);
-    const int k = len / 16 + 1;                                  // int(lengths[i] / 16 + 1), loss.py:26
+    const int len_raw = lengths[v];
+    const int len = len_raw < 0 ? 0 : (len_raw > T ? T : len_raw);
+    const int k = len_raw / 16 + 1;                              // int(lengths[i] / 16 + 1), loss.py:26 -- from the length as given
     const float x = (t < len) ? 1.0f / (1.0f + expf(-logits[(size_t)v * T + t])) : -1.0f;     // sigmoid is in (0, 1): -1 never wins
     s[t] = x;
     __syncthreads();
-    // rank of this element among the valid ones (ties broken by index: any choice among equal values gives the same mean)
     int rank = 0;
-    for (int u = 0; u < T; ++u) {
-        const float y = s[u];
-        rank += (y > x) || (y == x && u < t);
-    }
-    const int kk = k < len ? k : len;                            // topk raises for k > len (len = 0 never reaches the trainer)
-    float part = (t < len && rank < kk) ? x : 0.f;
+    for (int u = 0; u < T; ++u) rank += topk_before(s[u], u, x, t);
+    float part = (t < len && rank < k) ? x : 0.f;
     part = wave_sum(part);
     __shared__ float w[4];
     if ((t & 63) == 0) w[t >> 6] = part;
     __syncthreads();
-    if (t == 0) inst[v] = kk > 0 ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)kk : 0.f;
+    // torch.topk raises for k > len (a length beyond T, or <= 0): no exception can leave a kernel, the video's score is NaN instead
+    if (t == 0) inst[v] = (k <= len) ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)k : __builtin_nanf("");
 }
 
 // one wavefront per row: cosine / norm regulariser terms and the two KL sums of the row -> part[row][4]
@@ -153,31 +157,28 @@ __global__ __launch_bounds__(256) void iefvad_loss_finish_kernel(LossFinishArgs 
 // d total / d logits: one workgroup per video.  p = top-k mean as in the forward; BCE'(p) as torch's binary_cross_entropy
 // backward evaluates it, (p - y) / max((1 - p) p, 1e-12); each of the k selected snippets gets sigma'(x) / k of it.
 __global__ __launch_bounds__(256) void iefvad_mil_topk_grad_kernel(const float* logits, const int* lengths, const float* targets,
-                                                                   float* d_logits, int T, float scale_over_B) {
+                                                                   float* d_logits, int T, float scale_over_B, const float* scale_dev) {
     __shared__ float s[LOSS_T];
     __shared__ float w[4];
     const int v = blockIdx.x, t = threadIdx.x;
-    int len = lengths[v];
-    len = len < 0 ? 0 : (len > T ? T : len);
-    const int k = len / 16 + 1;
+    const int len_raw = lengths[v];
+    const int len = len_raw < 0 ? 0 : (len_raw > T ? T : len_raw);
+    const int k = len_raw / 16 + 1;
     const float x = (t < len) ? 1.0f / (1.0f + expf(-logits[(size_t)v * T + t])) : -1.0f;
     s[t] = x;
     __syncthreads();
     int rank = 0;
-    for (int u = 0; u < T; ++u) {
-        const float y = s[u];
-        rank += (y > x) || (y == x && u < t);
-    }
-    const int kk = k < len ? k : len;
-    const bool sel = t < len && rank < kk;
+    for (int u = 0; u < T; ++u) rank += topk_before(s[u], u, x, t);
+    const bool sel = t < len && rank < k;
     float part = sel ? x : 0.f;
     part = wave_sum(part);
     if ((t & 63) == 0) w[t >> 6] = part;
     __syncthreads();
-    const float p = kk > 0 ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)kk : 0.f;
+    const float p = (k <= len) ? ((w[0] + w[1]) + (w[2] + w[3])) / (float)k : __builtin_nanf("");
     const float y = targets[v];
-    const float dp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * scale_over_B;
-    d_logits[(size_t)v * T + t] = sel ? dp * (x * (1.0f - x)) / (float)kk : 0.f;
+    const float sc = scale_dev ? scale_over_B * scale_dev[0] : scale_over_B;
+    const float dp = (p - y) / fmaxf((1.0f - p) * p, 1e-12f) * sc;
+    d_logits[(size_t)v * T + t] = sel ? dp * (x * (1.0f - x)) / (float)k : 0.f;
 }
 
 // d total / d (mu_i, mu_e, logvar_i, logvar_e): one wavefront per row.
@@ -189,6 +190,7 @@ struct LossRowGradArgs {
     float* d_mu_i; float* d_mu_e; float* d_lv_i; float* d_lv_e;                     // [rows, 768], nullable each
     int rows;
     float lv_shift, lambda_reg, lambda_kl, scale;
+    const float* scale_dev;      // nullable: the upstream gradient as a device scalar (multiplies `scale`; no host read of it)
 };
 __global__ __launch_bounds__(256) void iefvad_loss_rows_grad_kernel(LossRowGradArgs a) {
     const int lane = threadIdx.x & 63;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void iefvad_loss_rows_grad_kernel(LossRowGradA
     float c1i, c2i, c1e, c2e;
     if (rni > 1e-12f) { c1i = al / rni; c2i = -(bi + al * dh - bi * hi * hi) / rni; } else { c1i = al * 1e12f; c2i = -bi * 1e12f; }
     if (rne > 1e-12f) { c1e = al / rne; c2e = -(be + al * dh - be * he * he) / rne; } else { c1e = al * 1e12f; c2e = -be * 1e12f; }
-    const float invR = a.scale / (float)a.rows, invRD = invR / (float)IEF_D;
+    const float invR = (a.scale_dev ? a.scale * a.scale_dev[0] : a.scale) / (float)a.rows, invRD = invR / (float)IEF_D;
     const float sg = rni > rne ? 1.f : (rni < rne ? -1.f : 0.f);
     const float cr = a.lambda_reg * invR, ck = a.lambda_kl * invRD;
     const float gni = rni > 0.f ? sg / rni : 0.f, gne = rne > 0.f ? -sg / rne : 0.f;      // d | |a| - |b| |: torch.norm's backward is 0 at 0
@@ -256,24 +258,25 @@ __global__ __launch_bounds__(256) void iefvad_loss_rows_grad_kernel(LossRowGradA
 
 // ---- optimiser step: torch.optim.AdamW as the trainers construct it (/root/reference/train/ucf_train.py:28, xd_train.py:25:
 // lr from the arguments, betas (0.9, 0.999), eps 1e-8, weight_decay 0.01, no amsgrad), single-tensor form, torch's operation order:
-//   p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
-// bc1 = 1 - b1^t and sqrt(bc2) = sqrt(1 - b2^t) come from the host (torch computes them in Python floats).
+//   p *= 1 - lr wd;  m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g;  p += -(lr / bc1) (m / (sqrt(v) / sqrt(bc2) + eps))
+// Every scalar (1 - lr wd, 1 - b1, 1 - b2, lr / (1 - b1^t), sqrt(1 - b2^t)) is formed on the HOST in double and rounded to fp32
+// once, as torch forms them in Python floats before they meet the fp32 tensors (1.0f - 0.999f would be 0.00099998713, torch
+// multiplies by fp32(0.001) = 0.0010000000475).
 struct AdamWArgs {
     float* p; const float* g; float* m; float* v;
     size_t n;
-    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+    float decay, w1, beta2, w2, step_size, bc2_sqrt, eps;
 };
 __global__ __launch_bounds__(256) void iefvad_adamw_kernel(AdamWArgs a) {
-    const float step_size = a.lr / a.bc1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = a.g[i];
         float p = a.p[i];
-        p = p * (1.0f - a.lr * a.weight_decay);
-        const float m = a.m[i] + (1.0f - a.beta1) * (g - a.m[i]);                  // lerp_(grad, 1 - beta1)
-        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * (g * g);            // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        p = p * a.decay;                                                           // mul_(1 - lr * weight_decay)
+        const float m = a.m[i] + a.w1 * (g - a.m[i]);                              // lerp_(grad, 1 - beta1)
+        const float v = a.beta2 * a.v[i] + a.w2 * (g * g);                         // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
         a.m[i] = m;
         a.v[i] = v;
-        a.p[i] = p - step_size * (m / denom);                                      // addcdiv_(exp_avg, denom, value = -step_size)
+        a.p[i] = p - a.step_size * (m / denom);                                    // addcdiv_(exp_avg, denom, value = -step_size)
     }
 }

@@ -1,0 +1,506 @@
+// Orchestration of the train-mode forward and of the model's backward pass (include/iefvad.h: iefvad_train_forward /
+// iefvad_train_backward; kernels in backward.h).  Included by iefvad.hip behind the handle, launch_proj and the error helpers.
+//
+// What the reference does per training step (/root/reference/train/ucf_train.py:43-106, train/xd_train.py:35-78): model.train(),
+// outputs = model(img, ev, None, prompt_text, lengths), the three loss terms, loss.backward(), optimizer.step().  Here:
+//   iefvad_train_forward   the forward of imf_vad.py:109-161 in train mode (attention dropout, imf_vad.py:70) that KEEPS what the
+//                          backward needs, in a caller-owned buffer:
+//                            per modality and layer: the layer input x_l, q | k | v (q pre-scaled by 1 / sqrt(96)), the attention
+//                            probabilities P (and their dropped copy), the attention output, the pre-LayerNorm sum;
+//                            the last LayerNorm output, the whitened rows, mu and logvar of both modalities;
+//                            the refinement states z_0 .. z_K and hidden activations h_0 .. h_{K-1}
+//   iefvad_train_backward  the gradients of every parameter, given the gradients of the eight outputs
+// Arithmetic: the dense projections of the forward run on the handle's kernels (fp32 MFMA, or the exact bf16x6 split when
+// the batch fills its grid); every product of the backward and the two attention products of the train forward run on
+// iefvad_bgemm_f32_kernel (fp32 MFMA).  Reductions over rows are fixed-order (no atomics): gradients are bit-reproducible.
+#pragma once
+
+// ---- layout of the caller's training buffer, in floats ----------------------------------------------------------------------------
+struct TrainLayout {
+    size_t U;                       // one [rows, 768] tensor
+    size_t PU;                      // one [B, 8, 256, 256] tensor
+    size_t x[2][IEFVAD_MAX_LAYERS + 1], qkv[2][IEFVAD_MAX_LAYERS], att[2][IEFVAD_MAX_LAYERS], s[2][IEFVAD_MAX_LAYERS];
+    size_t P[2][IEFVAD_MAX_LAYERS], Pd[2][IEFVAD_MAX_LAYERS];
+    size_t E[2], mu[2], lv[2];
+    size_t z[IEFVAD_MAX_STEPS + 1], hid[IEFVAD_MAX_STEPS];
+    size_t logits;
+    // backward scratch
+    size_t g, da, dh[2], gx, datt, dqkv, dP, part, cpart, rpart;
+    size_t part_floats, cpart_floats, rpart_floats;
+    size_t total;
+};
+
+static const int kColsumRows = 128;
+
+static int splitk_splits(int rows, int n_out) {
+    const int tiles = (n_out / 128) * (IEF_D / 128);
+    int want = (1024 + tiles - 1) / tiles, s = 1;
+    while (s < want && s < 64) s <<= 1;
+    while (s > 1 && ((rows / 16) % s)) s >>= 1;
+    return s;
+}
+
+static TrainLayout train_layout(int L, int K, int B) {
+    TrainLayout t;
+    memset(&t, 0, sizeof(t));
+    const size_t rows = (size_t)B * IEF_T;
+    t.U = rows * IEF_D;
+    t.PU = (size_t)B * IEF_H * IEF_T * IEF_T;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l <= L; ++l) t.x[m][l] = take(t.U);
+        for (int l = 0; l < L; ++l) {
+            t.qkv[m][l] = take(3 * t.U);
+            t.att[m][l] = take(t.U);
+            t.s[m][l] = take(t.U);
+            t.P[m][l] = take(t.PU);
+            t.Pd[m][l] = take(t.PU);
+        }
+        t.E[m] = take(t.U);
+        t.mu[m] = take(t.U);
+        t.lv[m] = take(t.U);
+    }
+    for (int k = 0; k <= K; ++k) t.z[k] = take(t.U);
+    for (int k = 0; k < K; ++k) t.hid[k] = take(t.U);
+    t.logits = take(rows);
+    t.g = take(t.U);
+    t.da = take(t.U);
+    t.dh[0] = take(2 * t.U);
+    t.dh[1] = take(2 * t.U);
+    t.gx = take(t.U);
+    t.datt = take(t.U);
+    t.dqkv = take(3 * t.U);
+    t.dP = take(t.PU);
+    size_t pf = 0;
+    const int nouts[3] = {IEF_D, 2 * IEF_D, 3 * IEF_D};
+    for (int n : nouts) {
+        const size_t f = (size_t)splitk_splits((int)rows, n) * n * IEF_D;
+        if (f > pf) pf = f;
+    }
+    t.part_floats = pf;
+    t.part = take(pf);
+    t.cpart_floats = ((rows + kColsumRows - 1) / kColsumRows) * 3 * IEF_D;
+    t.cpart = take(t.cpart_floats);
+    t.rpart_floats = ((rows + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK) * (2 * IEF_D + 1);
+    t.rpart = take(t.rpart_floats);
+    t.total = o;
+    return t;
+}
+
+extern "C" size_t iefvad_train_workspace_bytes(const iefvad_handle* h, int32_t B) {
+    if (!h || B <= 0 || B > 4096) return 0;
+    return train_layout(h->cfg.num_layers, h->cfg.num_steps, B).total * sizeof(float) + 256;
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------------------------------------------
+static int launch_bgemm(const BgemmArgs& a, bool akc, bool bkc, int nz, hipStream_t stream) {
+    const int bn = (a.N % 128 == 0) ? 128 : 96;
+    if (a.M % BG_BM || a.N % bn || a.K % BG_BK || a.M <= 0 || a.N <= 0 || a.K <= 0 || nz <= 0 || a.nz2 <= 0)
+        return fail("bgemm: shape M=%d N=%d K=%d is not a multiple of the 128 x %d x 16 tile", a.M, a.N, a.K, bn);
+    if ((a.lda | a.ldb) & 3) return fail("bgemm: leading dimensions must be multiples of 4 floats");
+    dim3 grid((a.M / BG_BM) * (a.N / bn), 1, nz);
+#define BG_LAUNCH(AK, BK_, BN_) hipLaunchKernelGGL((iefvad_bgemm_f32_kernel<AK, BK_, BN_>), grid, dim3(256), 0, stream, a)
+    if (bn == 128) {
+        if (akc && bkc) BG_LAUNCH(true, true, 128);
+        else if (akc) BG_LAUNCH(true, false, 128);
+        else if (bkc) BG_LAUNCH(false, true, 128);
+        else BG_LAUNCH(false, false, 128);
+    } else {
+        if (akc && bkc) BG_LAUNCH(true, true, 96);
+        else if (akc) BG_LAUNCH(true, false, 96);
+        else if (bkc) BG_LAUNCH(false, true, 96);
+        else BG_LAUNCH(false, false, 96);
+    }
+#undef BG_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// dX[rows, n_in] = alpha * dY[rows, n_out] * W[n_out, n_in] (+ R) (gated by G): the input gradient of a Linear whose weight is stored
+// [out, in] as torch stores it
+static int launch_dx(const float* dY, int ldy, const float* W, int n_out, int n_in, float* dX, const float* R, const float* G, float alpha,
+                     int rows, hipStream_t stream) {
+    BgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dY; a.B = W; a.C = dX; a.R = R; a.G = G;
+    a.M = rows; a.N = n_in; a.K = n_out; a.lda = ldy; a.ldb = n_in; a.ldc = n_in; a.nz2 = 1; a.alpha = alpha;
+    return launch_bgemm(a, true, false, 1, stream);
+}
+
+// dW[n_out, 768] = alpha * dY^T X over the rows, split-K with fixed-order reduction; dW may be null (frozen parameter).
+// `dW2` (nullable) receives rows [n_split, n_out) as a tensor of its own (the stacked mu | logvar heads).
+static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float* dW, float* dW2, int n_split, float alpha, int rows,
+                     float* part, size_t part_floats, hipStream_t stream) {
+    if (!dW && !dW2) return 0;
+    const int splits = splitk_splits(rows, n_out);
+    const size_t per = (size_t)n_out * IEF_D;
+    if ((size_t)splits * per > part_floats) return fail("train_backward: split-K scratch too small");
+    const int ms = rows / splits;
+    BgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dY; a.B = X; a.C = part;
+    a.M = n_out; a.N = IEF_D; a.K = ms; a.lda = ldy; a.ldb = IEF_D; a.ldc = IEF_D;
+    a.a1 = (long long)ms * ldy; a.b1 = (long long)ms * IEF_D; a.c1 = (long long)per; a.nz2 = 1; a.alpha = 1.f;
+    if (int rc = launch_bgemm(a, false, false, splits, stream)) return rc;
+    if (dW) {
+        const size_t n = (size_t)(n_split > 0 ? n_split : n_out) * IEF_D;
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, per, splits, n, dW, alpha);
+    }
+    if (dW2) {
+        const size_t n = (size_t)(n_out - n_split) * IEF_D;
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
+                           per, splits, n, dW2, alpha);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// db[ncols] = alpha * column sums of Y[rows, ld]; db2 (nullable) takes columns [n_split, ncols)
+static int launch_db(const float* Y, int ld, int ncols, float* db, float* db2, int n_split, float alpha, int rows, float* cpart,
+                     hipStream_t stream) {
+    if (!db && !db2) return 0;
+    const int nblk = (rows + kColsumRows - 1) / kColsumRows;
+    hipLaunchKernelGGL(iefvad_colsum_kernel, dim3((ncols + 255) / 256, nblk), dim3(256), 0, stream, Y, ld, rows, ncols, kColsumRows, cpart);
+    if (db) {
+        const size_t n = n_split > 0 ? n_split : ncols;
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cpart, (size_t)ncols, nblk, n, db, alpha);
+    }
+    if (db2) {
+        const size_t n = ncols - n_split;
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cpart + n_split, (size_t)ncols, nblk,
+                           n, db2, alpha);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// What a train-mode forward leaves on the handle for its backward: which buffer it filled, at which batch size, and whether the
+// dropped copy of the probabilities exists.  A handful of forwards may be outstanding (one record per training buffer).
+struct TrainRecord { const void* ws; int B; bool drop[2][IEFVAD_MAX_LAYERS]; unsigned long long stamp; };
+struct TrainState { TrainRecord rec[8]; unsigned long long clock = 0; };
+
+static void release_train(iefvad_handle* h) {
+    delete h->train;
+    h->train = nullptr;
+}
+
+static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t ws_bytes, const char* who) {
+    if (!h) return fail("%s: null handle", who);
+    if (!h->weights_set) return fail("%s: weights not set", who);
+    if (h->cfg.compute != IEFVAD_COMPUTE_F32 && h->cfg.compute != IEFVAD_COMPUTE_BF16X6)
+        return fail("%s: training runs in the fp32-accurate arithmetics only (compute f32 or bf16x6)", who);
+    if (B <= 0 || B > 4096) return fail("%s: B = %d outside 1..4096", who, B);
+    if (!ws || ws_bytes < iefvad_train_workspace_bytes(h, B))
+        return fail("%s: training buffer too small (%zu < %zu bytes)", who, ws_bytes, iefvad_train_workspace_bytes(h, B));
+    if ((uintptr_t)ws & 255) return fail("%s: the training buffer must be 256-byte aligned", who);
+    return 0;
+}
+
+// ---- train-mode forward -------------------------------------------------------------------------------------------------------------
+extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
+                                    const iefvad_train_options* opt, void* train_ws, size_t train_ws_bytes, const iefvad_outputs* out,
+                                    void* stream_) {
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_forward")) return rc;
+    if (!img || !ev || !out || !opt) return fail("iefvad_train_forward: null argument");
+    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
+        return fail("iefvad_train_forward: unknown in_dtype %d", in_dtype);
+    if (((uintptr_t)img | (uintptr_t)ev) & 15) return fail("iefvad_train_forward: buffers must be 16-byte aligned");
+    const iefvad_config& c = h->cfg;
+    const int L = c.num_layers, K = c.num_steps;
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < L; ++l)
+            if (!(opt->dropout_p[m][l] >= 0.f && opt->dropout_p[m][l] < 1.f))
+                return fail("iefvad_train_forward: dropout_p[%d][%d] = %g outside [0, 1)", m, l, (double)opt->dropout_p[m][l]);
+    hipStream_t stream = (hipStream_t)stream_;
+    const TrainLayout t = train_layout(L, K, B);
+    float* ws = (float*)train_ws;
+    const int rows = B * IEF_T;
+    Timer tm;
+    if (!h->train) {
+        h->train = new (std::nothrow) TrainState();
+        if (!h->train) return fail("iefvad_train_forward: out of host memory");
+        memset(h->train->rec, 0, sizeof(h->train->rec));
+    }
+    {   // the record of this forward replaces the one of the same buffer, else the oldest
+        TrainState& ts = *h->train;
+        int slot = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (ts.rec[i].ws == train_ws) { slot = i; break; }
+            if (ts.rec[i].stamp < ts.rec[slot].stamp) slot = i;
+        }
+        TrainRecord& r = ts.rec[slot];
+        r.ws = train_ws; r.B = B; r.stamp = ++ts.clock;
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) r.drop[m][l] = l < L && (opt->dropout_p[m][l] > 0.f || opt->keep_mask);
+    }
+    const bool splitmb = c.compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, IEF_D, IEF_D, 1);
+    const float qscale = 1.0f / sqrtf((float)IEF_DH);
+    const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;
+
+    // `.to(torch.float)` (imf_vad.py:41-42) into the saved layer-0 inputs
+    if (in_dtype == IEFVAD_IN_F32) {
+        HIP_TRY(hipMemcpyAsync(ws + t.x[0][0], img, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ws + t.x[1][0], ev, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    } else {
+        const int rc = (in_dtype == IEFVAD_IN_F16)
+                           ? launch_cast<__half>(img, ev, ws + t.x[0][0], ws + t.x[1][0], nullptr, nullptr, t.U, 2, stream)
+                           : launch_cast<__hip_bfloat16>(img, ev, ws + t.x[0][0], ws + t.x[1][0], nullptr, nullptr, t.U, 2, stream);
+        if (rc) return rc;
+    }
+
+    for (int l = 0; l < L; ++l) {
+        Proj p;
+        memset(&p, 0, sizeof(p));
+        p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
+        p.alpha = qscale;                               // q * 1/sqrt(dh) before the bmm, as F.multi_head_attention_forward does
+        for (int m = 0; m < 2; ++m) {
+            p.A32[m] = ws + t.x[m][l]; p.W32[m] = h->in_w[m][l]; p.Ws[m] = h->in_ws[m][l]; p.bias[m] = h->in_b[m][l];
+            p.C[m] = ws + t.qkv[m][l];
+        }
+        if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
+
+        for (int m = 0; m < 2; ++m) {
+            float* qkv = ws + t.qkv[m][l];
+            const float pdrop = opt->dropout_p[m][l];
+            const bool drop = pdrop > 0.f || opt->keep_mask;
+            // S = q k^T per (chunk, head)
+            BgemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.A = qkv; a.B = qkv + IEF_D; a.C = ws + t.P[m][l];
+            a.M = IEF_T; a.N = IEF_T; a.K = IEF_DH; a.lda = a.ldb = 3 * IEF_D; a.ldc = IEF_T;
+            a.a1 = a.b1 = (long long)IEF_T * 3 * IEF_D; a.a2 = a.b2 = IEF_DH;
+            a.c1 = (long long)IEF_H * IEF_T * IEF_T; a.c2 = (long long)IEF_T * IEF_T; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (int rc = launch_bgemm(a, true, true, B * IEF_H, stream)) return rc;
+            SoftmaxDropArgs sa;
+            sa.S = ws + t.P[m][l];
+            sa.Pd = drop ? ws + t.Pd[m][l] : nullptr;
+            sa.keep = opt->keep_mask ? opt->keep_mask + ((size_t)m * L + l) * t.PU : nullptr;
+            sa.seed = opt->seed * 0x100000001B3ull + (unsigned long long)(m * IEFVAD_MAX_LAYERS + l + 1) * 0x9E3779B97F4A7C15ull;
+            sa.p = pdrop;
+            sa.rows = (long long)B * IEF_H * IEF_T;
+            hipLaunchKernelGGL(iefvad_softmax_dropout_kernel, dim3((unsigned)((sa.rows + 3) / 4)), dim3(256), 0, stream, sa);
+            HIP_TRY(hipGetLastError());
+            // attention output = dropout(P) v
+            memset(&a, 0, sizeof(a));
+            a.A = drop ? ws + t.Pd[m][l] : ws + t.P[m][l]; a.B = qkv + 2 * IEF_D; a.C = ws + t.att[m][l];
+            a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = 3 * IEF_D; a.ldc = IEF_D;
+            a.a1 = (long long)IEF_H * IEF_T * IEF_T; a.a2 = (long long)IEF_T * IEF_T;
+            a.b1 = (long long)IEF_T * 3 * IEF_D; a.b2 = IEF_DH; a.c1 = (long long)IEF_T * IEF_D; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (int rc = launch_bgemm(a, true, false, B * IEF_H, stream)) return rc;
+        }
+
+        memset(&p, 0, sizeof(p));
+        p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
+        for (int m = 0; m < 2; ++m) {
+            p.A32[m] = ws + t.att[m][l]; p.W32[m] = h->out_w[m][l]; p.Ws[m] = h->out_ws[m][l]; p.bias[m] = h->out_b[m][l];
+            p.C[m] = ws + t.s[m][l]; p.R[m] = ws + t.x[m][l];
+        }
+        if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_OUT)) return rc;
+
+        LnArgs la;
+        memset(&la, 0, sizeof(la));
+        la.nrows = rows; la.eps = 1e-5f;
+        for (int m = 0; m < 2; ++m) {
+            la.x[m] = ws + t.s[m][l]; la.g1[m] = h->norm_w[m][l]; la.b1[m] = h->norm_b[m][l]; la.y[m] = ws + t.x[m][l + 1];
+        }
+        hipLaunchKernelGGL(iefvad_layernorm_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES, 2), dim3(256), 0, stream, la);
+        HIP_TRY(hipGetLastError());
+    }
+    {   // whitening LayerNorm (imf_vad.py:117,123) as a launch of its own: the backward needs its input, the last norm's output
+        LnArgs la;
+        memset(&la, 0, sizeof(la));
+        la.nrows = rows; la.eps = 1e-5f;
+        for (int m = 0; m < 2; ++m) {
+            la.x[m] = ws + t.x[m][L]; la.g1[m] = h->whiten_w[m]; la.b1[m] = h->whiten_b[m]; la.y[m] = ws + t.E[m];
+        }
+        hipLaunchKernelGGL(iefvad_layernorm_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES, 2), dim3(256), 0, stream, la);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Proj p;
+        memset(&p, 0, sizeof(p));
+        p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
+        for (int m = 0; m < 2; ++m) {
+            p.A32[m] = ws + t.E[m]; p.W32[m] = h->head_w[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
+            p.C[m] = ws + t.mu[m]; p.C2[m] = ws + t.lv[m];
+        }
+        if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_HEAD)) return rc;
+    }
+    {
+        FusionArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.mu_i = ws + t.mu[0]; fa.lv_i = ws + t.lv[0]; fa.mu_e = ws + t.mu[1]; fa.lv_e = ws + t.lv[1];
+        fa.n_i = out->w_i; fa.n_e = out->w_e; fa.z = ws + t.z[0];
+        fa.n_i_mean = out->w_i_mean; fa.n_e_mean = out->w_e_mean;
+        fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
+        hipLaunchKernelGGL(iefvad_fusion_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int k = 0; k < K; ++k) {
+        Proj p;
+        memset(&p, 0, sizeof(p));
+        p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
+        p.A32[0] = ws + t.z[k]; p.W32[0] = h->ref_w1[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k]; p.C[0] = ws + t.hid[k];
+        if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
+        memset(&p, 0, sizeof(p));
+        p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
+        p.A32[0] = ws + t.hid[k]; p.W32[0] = h->ref_w2[k]; p.Ws[0] = h->ref_w2s[k]; p.bias[0] = h->ref_b2[k];
+        p.C[0] = ws + t.z[k + 1]; p.R[0] = ws + t.z[k];
+        if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
+    }
+    float* logits = out->logits ? out->logits : ws + t.logits;
+    hipLaunchKernelGGL(iefvad_scorer_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, ws + t.z[K], h->cls_w, h->cls_b,
+                       logits, rows);
+    HIP_TRY(hipGetLastError());
+    // the caller's copies of the dict entries (imf_vad.py:152-161)
+    const struct { float* dst; size_t src; } cp[5] = {{out->fused, t.z[K]}, {out->image_mu, t.mu[0]}, {out->event_mu, t.mu[1]},
+                                                       {out->image_logvar, t.lv[0]}, {out->event_logvar, t.lv[1]}};
+    for (const auto& e : cp)
+        if (e.dst) HIP_TRY(hipMemcpyAsync(e.dst, ws + e.src, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------------------------
+extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws, size_t train_ws_bytes, const iefvad_output_grads* dout,
+                                     const iefvad_weight_grads* dw, void* stream_) {
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_backward")) return rc;
+    if (!dout || !dw) return fail("iefvad_train_backward: null argument");
+    const TrainRecord* rec = nullptr;
+    if (h->train)
+        for (int i = 0; i < 8; ++i)
+            if (h->train->rec[i].ws == train_ws && h->train->rec[i].stamp) rec = &h->train->rec[i];
+    if (!rec || rec->B != B) return fail("iefvad_train_backward: no iefvad_train_forward with B = %d has filled this training buffer", B);
+    const iefvad_config& c = h->cfg;
+    const int L = c.num_layers, K = c.num_steps;
+    hipStream_t stream = (hipStream_t)stream_;
+    const TrainLayout t = train_layout(L, K, B);
+    float* ws = (float*)train_ws;
+    const int rows = B * IEF_T;
+    const int nblk = (rows + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK;
+    const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;
+    const float qscale = 1.0f / sqrtf((float)IEF_DH);
+    float* part = ws + t.part;
+    float* cpart = ws + t.cpart;
+    float* rpart = ws + t.rpart;
+    float* g = ws + t.g;
+    float* da = ws + t.da;
+
+    // classifier (imf_vad.py:150)
+    {
+        ScorerBwdArgs sa;
+        sa.dlogit = dout->logits; sa.dfused = dout->fused; sa.z = ws + t.z[K]; sa.w = h->cls_w; sa.g = g;
+        sa.part_w = rpart; sa.part_b = rpart + (size_t)nblk * IEF_D; sa.rows = rows;
+        hipLaunchKernelGGL(iefvad_scorer_bwd_kernel, dim3(nblk), dim3(256), 0, stream, sa);
+        if (dw->cls_w)
+            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dw->cls_w, 1.f);
+        if (dw->cls_b)
+            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(1), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)1, nblk, (size_t)1,
+                               dw->cls_b, 1.f);
+        HIP_TRY(hipGetLastError());
+    }
+    // refinement steps, last to first (imf_vad.py:146-149): z_{k+1} = z_k - lambda (W2 relu(W1 z_k + b1) + b2); g = d z_{k+1}
+    for (int k = K - 1; k >= 0; --k) {
+        const float nl = -c.lambda_ref;
+        if (int rc = launch_dw(g, IEF_D, IEF_D, ws + t.hid[k], dw->ref_w2[k], nullptr, 0, nl, rows, part, t.part_floats, stream)) return rc;
+        if (int rc = launch_db(g, IEF_D, IEF_D, dw->ref_b2[k], nullptr, 0, nl, rows, cpart, stream)) return rc;
+        // d a = (-lambda g W2) gated by h > 0  (ReLU backward on the saved activation)
+        if (int rc = launch_dx(g, IEF_D, h->ref_w2[k], IEF_D, IEF_D, da, nullptr, ws + t.hid[k], nl, rows, stream)) return rc;
+        if (int rc = launch_dw(da, IEF_D, IEF_D, ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream)) return rc;
+        if (int rc = launch_db(da, IEF_D, IEF_D, dw->ref_b1[k], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+        // d z_k = g + d a W1   (in place: every element of g is read by the thread that overwrites it)
+        if (int rc = launch_dx(da, IEF_D, h->ref_w1[k], IEF_D, IEF_D, g, g, nullptr, 1.f, rows, stream)) return rc;
+    }
+    // fusion (imf_vad.py:130-144) -> d mu | d logvar of both modalities, stacked
+    {
+        FusionBwdArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.mu_i = ws + t.mu[0]; fa.lv_i = ws + t.lv[0]; fa.mu_e = ws + t.mu[1]; fa.lv_e = ws + t.lv[1];
+        fa.gz = g;
+        fa.d_mu_i = dout->image_mu; fa.d_lv_i = dout->image_logvar; fa.d_mu_e = dout->event_mu; fa.d_lv_e = dout->event_logvar;
+        fa.d_n_i = dout->w_i; fa.d_n_e = dout->w_e;
+        fa.dh_i = ws + t.dh[0]; fa.dh_e = ws + t.dh[1];
+        fa.rows = rows; fa.factor = factor; fa.eps = c.epsilon;
+        hipLaunchKernelGGL(iefvad_fusion_bwd_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int m = 0; m < 2; ++m) {
+        const float* dhm = ws + t.dh[m];
+        float* gx = ws + t.gx;
+        // heads (imf_vad.py:125-128): mu.weight | logvar.weight are stacked [1536, 768] in the handle
+        if (int rc = launch_dw(dhm, 2 * IEF_D, 2 * IEF_D, ws + t.E[m], dw->mu_w[m], dw->logvar_w[m], IEF_D, 1.f, rows, part, t.part_floats, stream))
+            return rc;
+        if (int rc = launch_db(dhm, 2 * IEF_D, 2 * IEF_D, dw->mu_b[m], dw->logvar_b[m], IEF_D, 1.f, rows, cpart, stream)) return rc;
+        if (int rc = launch_dx(dhm, 2 * IEF_D, h->head_w[m], 2 * IEF_D, IEF_D, gx, nullptr, nullptr, 1.f, rows, stream)) return rc;
+        // whitening LayerNorm (imf_vad.py:117,123), then the layers last to first
+        auto ln_bwd = [&](const float* x, const float* gamma, float* dgamma, float* dbeta) -> int {
+            LnBwdArgs la;
+            la.x = x; la.dy = gx; la.g = gamma; la.dx = gx; la.part_g = rpart; la.part_b = rpart + (size_t)nblk * IEF_D; la.rows = rows; la.eps = 1e-5f;
+            hipLaunchKernelGGL(iefvad_layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, stream, la);
+            if (dgamma)
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dgamma, 1.f);
+            if (dbeta)
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)IEF_D, nblk,
+                                   (size_t)IEF_D, dbeta, 1.f);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        if (int rc = ln_bwd(ws + t.x[m][L], h->whiten_w[m], dw->whiten_w[m], dw->whiten_b[m])) return rc;
+        for (int l = L - 1; l >= 0; --l) {
+            // x_{l+1} = LayerNorm(s_l), s_l = x_l + out_proj(attention(x_l))   (imf_vad.py:115-116)
+            if (int rc = ln_bwd(ws + t.s[m][l], h->norm_w[m][l], dw->norm_w[m][l], dw->norm_b[m][l])) return rc;
+            // gx = d s_l
+            float* datt = ws + t.datt;
+            float* dqkv = ws + t.dqkv;
+            float* dP = ws + t.dP;
+            const float* qkv = ws + t.qkv[m][l];
+            const float* P = ws + t.P[m][l];
+            // Pd is P when neither a dropout probability nor a mask was in force in the forward
+            const float* Pd = rec->drop[m][l] ? ws + t.Pd[m][l] : P;
+            if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream)) return rc;
+            if (int rc = launch_db(gx, IEF_D, IEF_D, dw->out_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+            if (int rc = launch_dx(gx, IEF_D, h->out_w[m][l], IEF_D, IEF_D, datt, nullptr, nullptr, 1.f, rows, stream)) return rc;
+            const long long sQ = (long long)IEF_T * 3 * IEF_D, sP1 = (long long)IEF_H * IEF_T * IEF_T, sP2 = (long long)IEF_T * IEF_T,
+                            sA = (long long)IEF_T * IEF_D;
+            BgemmArgs a;
+            // d Pd = d att v^T
+            memset(&a, 0, sizeof(a));
+            a.A = datt; a.B = qkv + 2 * IEF_D; a.C = dP;
+            a.M = IEF_T; a.N = IEF_T; a.K = IEF_DH; a.lda = IEF_D; a.ldb = 3 * IEF_D; a.ldc = IEF_T;
+            a.a1 = sA; a.a2 = IEF_DH; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sP1; a.c2 = sP2; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (int rc = launch_bgemm(a, true, true, B * IEF_H, stream)) return rc;
+            // d v = Pd^T d att
+            memset(&a, 0, sizeof(a));
+            a.A = Pd; a.B = datt; a.C = dqkv + 2 * IEF_D;
+            a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = IEF_D; a.ldc = 3 * IEF_D;
+            a.a1 = sP1; a.a2 = sP2; a.b1 = sA; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
+            // d S = Pd .* d Pd - P rowsum(Pd .* d Pd)
+            {
+                const long long srows = (long long)B * IEF_H * IEF_T;
+                hipLaunchKernelGGL(iefvad_softmax_bwd_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, stream, P, Pd, dP, srows);
+                HIP_TRY(hipGetLastError());
+            }
+            // d q (before the 1/sqrt(96) scale) = qscale * d S k
+            memset(&a, 0, sizeof(a));
+            a.A = dP; a.B = qkv + IEF_D; a.C = dqkv;
+            a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = 3 * IEF_D; a.ldc = 3 * IEF_D;
+            a.a1 = sP1; a.a2 = sP2; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = qscale;
+            if (int rc = launch_bgemm(a, true, false, B * IEF_H, stream)) return rc;
+            // d k = d S^T q_scaled
+            memset(&a, 0, sizeof(a));
+            a.A = dP; a.B = qkv; a.C = dqkv + IEF_D;
+            a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = 3 * IEF_D; a.ldc = 3 * IEF_D;
+            a.a1 = sP1; a.a2 = sP2; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
+            // in_proj (packed q | k | v, imf_vad.py:69-72)
+            if (int rc = launch_dw(dqkv, 3 * IEF_D, 3 * IEF_D, ws + t.x[m][l], dw->in_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream))
+                return rc;
+            if (int rc = launch_db(dqkv, 3 * IEF_D, 3 * IEF_D, dw->in_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+            // d x_l = d s_l (residual) + d qkv W_in; the input features need no gradient
+            if (l > 0)
+                if (int rc = launch_dx(dqkv, 3 * IEF_D, h->in_w[m][l], 3 * IEF_D, IEF_D, gx, gx, nullptr, 1.f, rows, stream)) return rc;
+        }
+    }
+    return 0;
+}

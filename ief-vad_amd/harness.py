@@ -485,28 +485,30 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         pend, pend_chunks = [], 0
 
     with torch.no_grad():
-        for item in test_loader:
-            if ragged:
-                img, ev, cls, n = _unpack_rows(item, maxlen, dataset, label_map)
+        try:
+            for item in test_loader:
+                if ragged:
+                    img, ev, cls, n = _unpack_rows(item, maxlen, dataset, label_map)
+                    classes.append(cls)
+                    pend.append((img, ev, n))
+                    pend_chunks += n // maxlen + (1 if n % maxlen else 0) if n >= maxlen else 1
+                    if pend_chunks >= batch_chunks:
+                        flush()
+                    continue
+                img, ev, cls, n = _unpack_item(item, maxlen, dataset, label_map)
                 classes.append(cls)
+                if batch_chunks > 0 and skip_empty_chunks and n >= maxlen and n % maxlen == 0:
+                    img, ev = img[:-1], ev[:-1]               # the all-zero chunk (tools.py:105-112)
                 pend.append((img, ev, n))
-                pend_chunks += n // maxlen + (1 if n % maxlen else 0) if n >= maxlen else 1
-                if pend_chunks >= batch_chunks:
+                pend_chunks += img.shape[0]
+                if batch_chunks <= 0 or pend_chunks >= batch_chunks:
                     flush()
-                continue
-            img, ev, cls, n = _unpack_item(item, maxlen, dataset, label_map)
-            classes.append(cls)
-            if batch_chunks > 0 and skip_empty_chunks and n >= maxlen and n % maxlen == 0:
-                img, ev = img[:-1], ev[:-1]               # the all-zero chunk (tools.py:105-112)
-            pend.append((img, ev, n))
-            pend_chunks += img.shape[0]
-            if batch_chunks <= 0 or pend_chunks >= batch_chunks:
-                flush()
-        flush()
-        while inflight:
-            run_oldest()
-        if stage_pool is not None:
-            stage_pool.shutdown(wait=True)
+            flush()
+            while inflight:
+                run_oldest()
+        finally:
+            if stage_pool is not None:         # also when a forward raised: the worker thread must not outlive the call
+                stage_pool.shutdown(wait=True)
         if nl > 1:
             for s in streams:
                 torch.cuda.current_stream(device).wait_stream(s)

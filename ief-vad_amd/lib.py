@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IEFVAD_LIB") or os.path.join(_HERE, "libiefvad.so")      # IEFVAD_LIB: A/B builds of the same ABI (tools)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
@@ -27,7 +27,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
-           "iefvad_loss_workspace_bytes"]
+           "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -49,6 +49,20 @@ class Weights(C.Structure):
                 ("ref_w1", _fp * MAX_STEPS), ("ref_b1", _fp * MAX_STEPS),
                 ("ref_w2", _fp * MAX_STEPS), ("ref_b2", _fp * MAX_STEPS),
                 ("cls_w", _fp), ("cls_b", _fp)]
+
+
+class WeightGrads(C.Structure):
+    """iefvad_weight_grads: gradient destinations, field for field the layout of `Weights`."""
+    _fields_ = Weights._fields_
+
+
+class TrainOptions(C.Structure):
+    _fields_ = [("dropout_p", (C.c_float * MAX_LAYERS) * 2), ("seed", C.c_uint64), ("keep_mask", _fp)]
+
+
+class OutputGrads(C.Structure):
+    _fields_ = [("fused", _fp), ("logits", _fp), ("image_mu", _fp), ("event_mu", _fp),
+                ("image_logvar", _fp), ("event_logvar", _fp), ("w_i", _fp), ("w_e", _fp)]
 
 
 class Outputs(C.Structure):
@@ -113,9 +127,17 @@ def load_library() -> C.CDLL:
     lib.iefvad_loss_forward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.iefvad_loss_forward.restype = C.c_int
-    lib.iefvad_loss_backward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 6
+    lib.iefvad_loss_backward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7
     lib.iefvad_loss_backward.restype = C.c_int
-    lib.iefvad_adamw_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 5 + [C.c_int32, C.c_void_p]
+    lib.iefvad_train_workspace_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.iefvad_train_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_train_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(TrainOptions), C.c_void_p,
+                                         C.c_size_t, C.POINTER(Outputs), C.c_void_p]
+    lib.iefvad_train_forward.restype = C.c_int
+    lib.iefvad_train_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(OutputGrads), C.POINTER(WeightGrads),
+                                          C.c_void_p]
+    lib.iefvad_train_backward.restype = C.c_int
+    lib.iefvad_adamw_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_double] * 5 + [C.c_int32, C.c_void_p]
     lib.iefvad_adamw_step.restype = C.c_int
     lib.iefvad_host_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]
     lib.iefvad_host_gather.restype = C.c_int

@@ -12,8 +12,8 @@ shapes, computed by libiefvad (`iefvad_loss_forward` / `iefvad_loss_backward`, c
 
   * `AdamW(params, lr)` -- torch.optim.AdamW's update as the trainers construct it (ucf_train.py:28), `iefvad_adamw_step`.
 
-The model's own backward pass and the train-mode forward (attention dropout, imf_vad.py:70) are not part of this build: the
-gradients stop at the tensors `iefvad_amd.MMFMIL` returns.
+In train mode `iefvad_amd.MMFMIL` returns differentiable tensors (model.py: `_TrainForward`), so `training_loss(...).backward()`
+reaches every parameter: loss head backward here, the model's backward pass in `iefvad_train_backward`.
 """
 from __future__ import annotations
 
@@ -109,12 +109,14 @@ class _LossHead(torch.autograd.Function):
         need = list(ctx.needs_input_grad[:5])
         grads = [torch.empty_like(lg) if need[0] else None] + [torch.empty_like(hs[i]) if need[1 + i] else None for i in range(4)]
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        # the upstream gradient stays on the device: the kernels read the scalar themselves (no .item() sync per step)
+        gscale = grad_out.detach().reshape(1).to(device=dev, dtype=torch.float32).contiguous()
         lib = _lib.load_library()
         with torch.cuda.device(dev):
             rc = lib.iefvad_loss_backward(ptr(lg), ptr(hs[0]), ptr(hs[1]), ptr(hs[2]), ptr(hs[3]), ptr(lens), ptr(targets), B, T,
                                           _lib.NOISE_STUDENT_T if noise_model == "StudentT" else _lib.NOISE_GAUSSIAN, nu, lambda_reg,
-                                          lambda_kl, float(grad_out), ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]),
-                                          ptr(grads[4]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                          lambda_kl, 1.0, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]),
+                                          ptr(grads[4]), ptr(gscale), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc != 0:
             raise RuntimeError("iefvad_loss_backward: " + _lib.last_error())
         shaped = [g.reshape(x.shape).to(x.dtype) if g is not None else None
@@ -133,34 +135,56 @@ def training_loss(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, length
                            labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
 
 
-class AdamW:
-    """torch.optim.AdamW's update (the optimiser of /root/reference/train/ucf_train.py:28, xd_train.py:25) on device tensors,
-    one `iefvad_adamw_step` launch per tensor: `AdamW(params, lr)`, `.step()` reads each parameter's `.grad`, `.zero_grad()`.
-    State (`exp_avg`, `exp_avg_sq`, the per-parameter step counts) lives here; amsgrad, maximize and parameter groups are not offered."""
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW's update (the optimiser of /root/reference/train/ucf_train.py:28, xd_train.py:25) with the arithmetic in
+    libiefvad: one `iefvad_adamw_step` launch per parameter tensor, torch's operation order, hyper-parameter scalars formed in
+    double on the host as torch forms them.  A `torch.optim.Optimizer` subclass, so what the trainers do with their optimiser
+    works unchanged: `MultiStepLR(optimizer, ...)` (ucf_train.py:29-33), `optimizer.state_dict()` in the checkpoint
+    (ucf_train.py:141-149), `load_state_dict`, parameter groups, `zero_grad()`.  State per parameter as torch.optim.AdamW keeps
+    it (`step` as a CPU float tensor, `exp_avg`, `exp_avg_sq`), so a state_dict moves between the two optimisers.
+    amsgrad / maximize / capturable / fused are not offered."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
-        self.params = [p for p in params]
-        if any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
-            raise ValueError("AdamW: contiguous fp32 tensors on a HIP device only; there is no CPU fallback")
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
-        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in self.params]
-        self.steps = [0] * len(self.params)          # per parameter, as torch counts them: only steps that saw a gradient
-
-    def zero_grad(self):
-        for p in self.params:
-            p.grad = None
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("AdamW: invalid hyper-parameter")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if (not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise ValueError("AdamW: contiguous fp32 tensors on a HIP device only; there is no CPU fallback")
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         lib = _lib.load_library()
-        for i, (p, (m, v)) in enumerate(zip(self.params, self.state)):
-            if p.grad is None:
-                continue
-            self.steps[i] += 1
-            g = p.grad.contiguous().float()
-            with torch.cuda.device(p.device):
-                rc = lib.iefvad_adamw_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
-                                           C.c_void_p(v.data_ptr()), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                           self.weight_decay, self.steps[i], C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
-            if rc != 0:
-                raise RuntimeError("iefvad_adamw_step: " + _lib.last_error())
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise RuntimeError("iefvad_amd.losses.AdamW: amsgrad / maximize are not offered")
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)           # torch keeps it on the CPU for the default path
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.contiguous().float()
+                with torch.cuda.device(p.device):
+                    rc = lib.iefvad_adamw_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(st["exp_avg"].data_ptr()),
+                                               C.c_void_p(st["exp_avg_sq"].data_ptr()), p.numel(), float(group["lr"]), float(b1), float(b2),
+                                               float(group["eps"]), float(group["weight_decay"]), int(st["step"].item()),
+                                               C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+                if rc != 0:
+                    raise RuntimeError("iefvad_adamw_step: " + _lib.last_error())
+                # the kernel wrote through the raw pointer: tell autograd (and iefvad_amd.MMFMIL's weight cache) that p changed
+                torch.autograd.graph.increment_version(p)
+        return loss

@@ -12,6 +12,9 @@ Mirrors the interface of /root/reference/model/imf_vad.py:
 The modules below only HOLD parameters (same names, shapes and default initialisation as the
 torch.nn modules the reference instantiates); no torch op computes the forward.  Inputs must live
 on a HIP device: there is no CPU path, a CPU tensor raises.
+
+`model.train()` switches `forward` to the train-mode path (attention dropout, activations kept for the backward): the returned
+tensors are differentiable with respect to every parameter, `loss.backward()` runs `iefvad_train_backward`.
 """
 from __future__ import annotations
 
@@ -52,8 +55,9 @@ class _AttentionParams(nn.Module):
     order, in_proj_bias [3D], out_proj.{weight,bias}; same init order as torch (out_proj first, then
     xavier-uniform in_proj, zero biases) so a seeded construction reproduces the reference's weights."""
 
-    def __init__(self, dim: int):
+    def __init__(self, dim: int, dropout: float = 0.0):
         super().__init__()
+        self.dropout = dropout          # nn.MultiheadAttention.dropout: applied to the attention weights in train mode
         self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
         self.in_proj_bias = nn.Parameter(torch.empty(3 * dim))
         self.out_proj = _LinearParams(dim, dim)
@@ -86,9 +90,9 @@ class FusionParams(nn.Module):
         self.noise_model = noise_model
         self.nu = nu
         self.epsilon = epsilon
-        self.image_attn_layers = nn.ModuleList([_AttentionParams(embed_dim) for _ in range(num_layers)])
+        self.image_attn_layers = nn.ModuleList([_AttentionParams(embed_dim, dropout) for _ in range(num_layers)])
         self.image_norms = nn.ModuleList([_LayerNormParams(embed_dim) for _ in range(num_layers)])
-        self.event_attn_layers = nn.ModuleList([_AttentionParams(embed_dim) for _ in range(num_layers)])
+        self.event_attn_layers = nn.ModuleList([_AttentionParams(embed_dim, dropout) for _ in range(num_layers)])
         self.event_norms = nn.ModuleList([_LayerNormParams(embed_dim) for _ in range(num_layers)])
         self.whiten_image = _LayerNormParams(embed_dim)
         self.whiten_event = _LayerNormParams(embed_dim)
@@ -102,6 +106,85 @@ class FusionParams(nn.Module):
             self.refinement_blocks = nn.ModuleList(
                 [_RefinementBlockParams(embed_dim) for _ in range(num_refinement_steps)])
         self.classifier = _LinearParams(embed_dim, 1)
+
+
+class _TrainForward(torch.autograd.Function):
+    """The train-mode forward of the whole model as ONE autograd node: forward = `iefvad_train_forward` (keeps the activations in
+    a buffer this node owns), backward = `iefvad_train_backward` (every parameter gradient).  The parameters are inputs of the
+    node, so `loss.backward()` accumulates into their `.grad` exactly as with the reference's modules."""
+
+    @staticmethod
+    def forward(ctx, model, img, ev, *params):
+        lib = _lib.load_library()
+        t = model.temporal
+        device = img.device
+        B, T, D = img.shape
+        img = model._prepare_input(img)
+        ev = model._prepare_input(ev)
+        if ev.dtype != img.dtype:
+            img, ev = img.to(torch.float), ev.to(torch.float)
+        opt = _lib.TrainOptions()
+        for m, name in enumerate(("image", "event")):
+            for l, a in enumerate(getattr(t, f"{name}_attn_layers")):
+                opt.dropout_p[m][l] = float(a.dropout)
+        seed = model.__dict__.get("dropout_seed")
+        if seed is None:      # a fresh stream per step, reproducible under torch.manual_seed
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        opt.seed = seed & 0xFFFFFFFFFFFFFFFF
+        mask = model.__dict__.get("dropout_mask")
+        if mask is not None:
+            want = (2, t.num_layers, B, t.num_heads, T, T)
+            if tuple(mask.shape) != want or mask.dtype != torch.uint8 or mask.device != device or not mask.is_contiguous():
+                raise ValueError(f"dropout_mask must be a contiguous uint8 tensor of shape {want} on {device}")
+            opt.keep_mask = mask.data_ptr()
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            model._ensure_handle(device)
+            model._ensure_weights(device, stream)
+            need = lib.iefvad_train_workspace_bytes(model._handle, B)
+            if need == 0:
+                raise RuntimeError(f"iefvad_train_workspace_bytes: unsupported batch size {B}")
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            f32 = dict(dtype=torch.float32, device=device)
+            res = {k: torch.empty(B, T, 1 if k == "logits" else D, **f32) for k in OUTPUT_KEYS}
+            o = _lib.Outputs()
+            for k in OUTPUT_KEYS:
+                setattr(o, k, res[k].data_ptr())
+            rc = lib.iefvad_train_forward(model._handle, C.c_void_p(img.data_ptr()), C.c_void_p(ev.data_ptr()), _IN_DTYPES[img.dtype], B,
+                                          C.byref(opt), C.c_void_p(ws.data_ptr()), ws.numel(), C.byref(o), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("iefvad_train_forward: " + _lib.last_error())
+        ctx.model, ctx.ws, ctx.B, ctx.mask = model, ws, B, mask
+        ctx.params = params
+        return tuple(res[k] for k in OUTPUT_KEYS)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = _lib.load_library()
+        model, ws = ctx.model, ctx.ws
+        if ws is None:
+            raise RuntimeError("iefvad_amd.MMFMIL: backward through the same forward twice (the activations were released)")
+        device = ws.device
+        keep = []
+        dout = _lib.OutputGrads()
+        for k, g in zip(OUTPUT_KEYS, gouts):
+            if g is not None:
+                g = g.contiguous().float()
+                keep.append(g)
+                setattr(dout, k, g.data_ptr())
+        needs = ctx.needs_input_grad[3:]
+        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) if n else None for p, n in zip(ctx.params, needs)]
+        by_id = {id(p): g for p, g in zip(ctx.params, grads)}
+        dw = _lib.WeightGrads()
+        model._fill_weight_struct(dw, lambda p: by_id[id(p)].data_ptr() if by_id.get(id(p)) is not None else None)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = lib.iefvad_train_backward(model._handle, ctx.B, C.c_void_p(ws.data_ptr()), ws.numel(), C.byref(dout), C.byref(dw),
+                                           C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("iefvad_train_backward: " + _lib.last_error())
+        ctx.ws = None
+        return (None, None, None, *grads)
 
 
 class MMFMIL(nn.Module):
@@ -218,31 +301,36 @@ class MMFMIL(nn.Module):
                 raise RuntimeError("MMFMIL parameters must be contiguous fp32 tensors on the input's device "
                                    f"({device}); call model.to(device)")
         w = _lib.Weights()
-        for m, name in enumerate(("image", "event")):
-            attn = getattr(t, f"{name}_attn_layers")
-            norms = getattr(t, f"{name}_norms")
-            for l in range(t.num_layers):
-                w.in_proj_w[m][l] = attn[l].in_proj_weight.data_ptr()
-                w.in_proj_b[m][l] = attn[l].in_proj_bias.data_ptr()
-                w.out_proj_w[m][l] = attn[l].out_proj.weight.data_ptr()
-                w.out_proj_b[m][l] = attn[l].out_proj.bias.data_ptr()
-                w.norm_w[m][l] = norms[l].weight.data_ptr()
-                w.norm_b[m][l] = norms[l].bias.data_ptr()
-            wh = getattr(t, f"whiten_{name}")
-            w.whiten_w[m], w.whiten_b[m] = wh.weight.data_ptr(), wh.bias.data_ptr()
-            mu, lv = getattr(t, f"{name}_mu"), getattr(t, f"{name}_logvar")
-            w.mu_w[m], w.mu_b[m] = mu.weight.data_ptr(), mu.bias.data_ptr()
-            w.logvar_w[m], w.logvar_b[m] = lv.weight.data_ptr(), lv.bias.data_ptr()
-        for k in range(t.num_refinement_steps):
-            blk = t.refinement_blocks[k]
-            l1, l2 = getattr(blk, "0"), getattr(blk, "2")
-            w.ref_w1[k], w.ref_b1[k] = l1.weight.data_ptr(), l1.bias.data_ptr()
-            w.ref_w2[k], w.ref_b2[k] = l2.weight.data_ptr(), l2.bias.data_ptr()
-        w.cls_w, w.cls_b = t.classifier.weight.data_ptr(), t.classifier.bias.data_ptr()
+        self._fill_weight_struct(w, lambda p: p.data_ptr())
         rc = _lib.load_library().iefvad_set_weights(self._handle, C.byref(w), C.c_void_p(stream))
         if rc != 0:
             raise RuntimeError("iefvad_set_weights: " + _lib.last_error())
         self._weights_sig = sig
+
+    def _fill_weight_struct(self, w, ptr):
+        """Fill an `iefvad_weights`-shaped ctypes structure (Weights or WeightGrads) with `ptr(parameter)` per field."""
+        t = self.temporal
+        for m, name in enumerate(("image", "event")):
+            attn = getattr(t, f"{name}_attn_layers")
+            norms = getattr(t, f"{name}_norms")
+            for l in range(t.num_layers):
+                w.in_proj_w[m][l] = ptr(attn[l].in_proj_weight)
+                w.in_proj_b[m][l] = ptr(attn[l].in_proj_bias)
+                w.out_proj_w[m][l] = ptr(attn[l].out_proj.weight)
+                w.out_proj_b[m][l] = ptr(attn[l].out_proj.bias)
+                w.norm_w[m][l] = ptr(norms[l].weight)
+                w.norm_b[m][l] = ptr(norms[l].bias)
+            wh = getattr(t, f"whiten_{name}")
+            w.whiten_w[m], w.whiten_b[m] = ptr(wh.weight), ptr(wh.bias)
+            mu, lv = getattr(t, f"{name}_mu"), getattr(t, f"{name}_logvar")
+            w.mu_w[m], w.mu_b[m] = ptr(mu.weight), ptr(mu.bias)
+            w.logvar_w[m], w.logvar_b[m] = ptr(lv.weight), ptr(lv.bias)
+        for k in range(t.num_refinement_steps):
+            blk = t.refinement_blocks[k]
+            l1, l2 = getattr(blk, "0"), getattr(blk, "2")
+            w.ref_w1[k], w.ref_b1[k] = ptr(l1.weight), ptr(l1.bias)
+            w.ref_w2[k], w.ref_b2[k] = ptr(l2.weight), ptr(l2.bias)
+        w.cls_w, w.cls_b = ptr(t.classifier.weight), ptr(t.classifier.bias)
 
     def lanes(self, n: int):
         """`n` forward lanes over ONE set of parameters: lane 0 is this module, the others are shallow copies that share
@@ -254,6 +342,8 @@ class MMFMIL(nn.Module):
         while len(have) < n - 1:
             c = copy.copy(self)
             c.__dict__["_lane_copies"] = []
+            c.__dict__["_stagers"] = {}          # a lane stages through buffers of its own (harness.score_loader), never lane 0's
+            c.__dict__.pop("_param_slots", None)
             c._handle = c._handle_key = c._weights_sig = c._workspace = None
             have.append(c)
         return [self] + have[:max(n - 1, 0)]
@@ -283,10 +373,9 @@ class MMFMIL(nn.Module):
 
     def forward(self, img_visual, ev_visual, padding_mask=None, text=None, lengths=None, return_attn=False,
                 *, timed: bool = False) -> Dict[str, torch.Tensor]:
-        if self.training:
-            raise RuntimeError("iefvad_amd.MMFMIL is inference-only (the reference applies attention dropout in "
-                               "train mode); call model.eval() first")
         self._noise_code()   # ValueError for an unsupported noise_model, as the reference raises
+        if self.training:
+            return self._forward_train(img_visual, ev_visual)
         if not (img_visual.is_cuda and ev_visual.is_cuda):
             raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback "
                                "(move the inputs with .to('cuda'))")
@@ -339,6 +428,32 @@ class MMFMIL(nn.Module):
             return {k: res[k] for k in OUTPUT_KEYS}   # the reference's key order
         return res
 
+    # ------------------------------------------------------------------ train mode
+    def _forward_train(self, img_visual, ev_visual) -> Dict[str, torch.Tensor]:
+        """`model.train()` forward (/root/reference/train/ucf_train.py:43,60-66): the same dict, differentiable with respect to
+        every parameter -- `iefvad_train_forward` keeps the activations, `loss.backward()` reaches `iefvad_train_backward`
+        through `_TrainForward`.  Attention dropout (imf_vad.py:70) uses each layer's `.dropout` (as nn.MultiheadAttention
+        keeps it); the mask comes from the library's counter-based generator seeded from torch's RNG (`self.dropout_seed` pins
+        it), or from `self.dropout_mask` (uint8 [2, L, B, 8, T, T], 1 = keep) when a test injects one."""
+        if self.compute not in ("f32", "bf16x6"):
+            raise RuntimeError("iefvad_amd.MMFMIL trains in the fp32-accurate arithmetics only: compute='f32' or 'bf16x6'")
+        if not (img_visual.is_cuda and ev_visual.is_cuda):
+            raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback "
+                               "(move the inputs with .to('cuda'))")
+        if img_visual.shape != ev_visual.shape or img_visual.dim() != 3:
+            raise ValueError(f"expected two [B, T, D] tensors of equal shape, got {tuple(img_visual.shape)} and "
+                             f"{tuple(ev_visual.shape)}")
+        B, T, D = img_visual.shape
+        if T != self.visual_length or D != self.temporal.embed_dim:
+            raise ValueError(f"expected [B, {self.visual_length}, {self.temporal.embed_dim}] inputs, got [B, {T}, {D}]")
+        slots = self.__dict__.get("_param_slots")
+        if slots is None:
+            slots = [(m._parameters, n) for m in self.temporal.modules() for n in m._parameters if m._parameters[n] is not None]
+            self.__dict__["_param_slots"] = slots
+        params = [d[n] for d, n in slots]
+        outs = _TrainForward.apply(self, img_visual.detach(), ev_visual.detach(), *params)
+        return dict(zip(OUTPUT_KEYS, outs))
+
     def forward_videos(self, img_rows: torch.Tensor, ev_rows: torch.Tensor, lengths, nan_to_num: bool = True
                        ) -> Dict[str, torch.Tensor]:
         """Scores of whole videos (`iefvad_forward_videos`, include/iefvad.h): `img_rows`, `ev_rows` are the videos' VALID
@@ -346,7 +461,7 @@ class MMFMIL(nn.Module):
         chunker (tools.py:100-114), the conditional nan_to_num of test.py:90-95 and the `[0:len]` slicing of
         test.py:119-121,131-138 happen on the device.  Returns `logits`, `w_i_mean`, `w_e_mean`, each [sum(lengths)]."""
         if self.training:
-            raise RuntimeError("iefvad_amd.MMFMIL is inference-only; call model.eval() first")
+            raise RuntimeError("iefvad_amd.MMFMIL.forward_videos is an evaluation entry point; call model.eval() first")
         self._noise_code()
         if not (img_rows.is_cuda and ev_rows.is_cuda):
             raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback")

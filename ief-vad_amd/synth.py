@@ -160,3 +160,30 @@ def make_loss_inputs(seed: int, B: int = 8, T: int = 256, D: int = 768):
     labels[np.arange(B), cls] = 1.0
     lengths = np.array(LOSS_LENGTHS[:B], np.int64)
     return out, labels, lengths
+
+
+TRAIN_LENGTHS = [256, 100, 37, 256, 180, 16, 255, 64]
+
+
+def make_train_batch(seed: int, B: int, T: int = 256, D: int = 768):
+    """A seeded training batch in the shape the reference's trainers build (/root/reference/train/ucf_train.py:44-58): the first
+    half normal, the second half abnormal videos, each resampled / zero padded to T snippets by the train loader
+    (data/tools.py:89-97: `pad` leaves zeros behind a short video's `length` rows), one-hot labels [B, 14] with column 0 =
+    normal, lengths [B].  Returns (img, ev, labels, lengths) as numpy arrays."""
+    img, ev = make_inputs(seed, B, T, D)
+    lengths = np.array([TRAIN_LENGTHS[i % len(TRAIN_LENGTHS)] for i in range(B)], np.int64)
+    for i, n in enumerate(lengths):
+        img[i, n:] = 0
+        ev[i, n:] = 0
+    labels = np.zeros((B, 14), np.float32)
+    for i in range(B):
+        labels[i, 0 if i < (B + 1) // 2 else 1 + (3 * i) % 13] = 1.0
+    return img, ev, labels, lengths
+
+
+def make_dropout_mask(seed: int, L: int, B: int, p: float = 0.1, H: int = 8, T: int = 256) -> np.ndarray:
+    """Seeded keep mask of the attention dropout, uint8 [2 modalities, L, B, H, T, T] (1 = keep, probability 1 - p): what a test
+    injects into both the reference (through torch.nn.functional.dropout, tests/golden/make_golden.py) and
+    `iefvad_amd.MMFMIL.dropout_mask`."""
+    rng = np.random.default_rng([seed, 4242])
+    return (rng.random((2, L, B, H, T, T), dtype=np.float32) >= p).astype(np.uint8)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 4
+#define IEFVAD_ABI_VERSION 5
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -197,8 +197,10 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
  * The four 768-d pointers may all be NULL: then only out[0] (and out[7] = out[0]) is computed -- CLAS2 alone.
  * iefvad_loss_backward: the gradients of grad_scale * total with respect to logits [B, T] and the four 768-d tensors (what
  * `loss.backward()` hands to the model's outputs in /root/reference/train/ucf_train.py:103): CLAS2 through torch's BCE
- * backward ((p - y) / max((1 - p) p, 1e-12)) and the top-k selection, the cosine / norm regulariser, the KL terms.  Each
- * d_* pointer may be NULL (that gradient is not written).  The model's own backward pass is not part of this library. */
+ * backward ((p - y) / max((1 - p) p, 1e-12)) and the top-k selection, the cosine / norm regulariser, the KL terms.
+ * `grad_scale_dev` (nullable) is the upstream gradient as a DEVICE scalar that multiplies grad_scale inside the kernels, so an
+ * autograd node never has to read it back to the host.  Each
+ * d_* pointer may be NULL (that gradient is not written).  The model's own backward pass: iefvad_train_backward below. */
 size_t iefvad_loss_workspace_bytes(int32_t B, int32_t T);
 int iefvad_loss_forward(const float* logits, const float* image_mu, const float* event_mu, const float* image_logvar,
                         const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
@@ -208,13 +210,73 @@ int iefvad_loss_backward(const float* logits, const float* image_mu, const float
                          const float* event_logvar, const int32_t* lengths, const float* targets, int32_t B, int32_t T,
                          int32_t noise_model, float nu, float lambda_reg, float lambda_kl, float grad_scale,
                          float* d_logits, float* d_image_mu, float* d_event_mu, float* d_image_logvar,
-                         float* d_event_logvar, void* stream);
+                         float* d_event_logvar, const float* grad_scale_dev, void* stream);
+
+/* ---- training: the train-mode forward and the model's backward pass ----------------------------------------------
+ * What `model.train(); outputs = model(...); loss.backward()` does to the model in the reference's trainers
+ * (/root/reference/train/ucf_train.py:43,60-66,103; train/xd_train.py:37,46-52,78): the forward of
+ * /root/reference/model/imf_vad.py:109-161 with the attention dropout of nn.MultiheadAttention(dropout=0.1) (imf_vad.py:70) active,
+ * and the gradient of every parameter of SURVEY.md Appendix B.  The reference has no backward code of its own (autograd derives it);
+ * the entry points below are what a torch.autograd.Function around the model binds.
+ *
+ * iefvad_train_forward computes the eight outputs like iefvad_forward and keeps what the backward needs in `train_ws`
+ * (iefvad_train_workspace_bytes; 256-byte aligned; owned by the caller, who keeps it untouched until the matching
+ * iefvad_train_backward has run on the same stream).  compute must be IEFVAD_COMPUTE_F32 or IEFVAD_COMPUTE_BF16X6 (fp32-accurate);
+ * the whole batch runs as one pass (B <= 4096).
+ *   dropout_p[m][l]  the probability nn.MultiheadAttention m / layer l drops an attention weight with (0 = none); kept weights
+ *                    are scaled by 1 / (1 - p) as torch.nn.functional.dropout does
+ *   seed             stream of the library's counter-based mask generator for this step.  torch draws its mask from its own Philox
+ *                    stream, so a p > 0 run is statistically, not bit-wise, the reference's; p = 0 and injected masks are exact
+ *   keep_mask        device, nullable: uint8 [2][L][B][8][T][T], 1 = keep -- an injected mask replaces the generator (tests, replay)
+ * iefvad_train_backward: `dout` holds the gradients handed to the eight outputs (each nullable = zero; [B*T, D], logits [B*T]);
+ * every non-null pointer of `dw` ([same shape as the parameter], fp32) receives that parameter's gradient (overwritten, not
+ * accumulated).  Reductions over rows are fixed-order: the same inputs give the same bits on every run. */
+typedef struct iefvad_train_options {
+    float dropout_p[2][IEFVAD_MAX_LAYERS];
+    uint64_t seed;
+    const uint8_t* keep_mask;
+} iefvad_train_options;
+
+typedef struct iefvad_output_grads {
+    const float* fused;  const float* logits;  const float* image_mu;  const float* event_mu;
+    const float* image_logvar;  const float* event_logvar;  const float* w_i;  const float* w_e;
+} iefvad_output_grads;
+
+/* gradient destinations, field for field the layout of iefvad_weights */
+typedef struct iefvad_weight_grads {
+    float* in_proj_w[2][IEFVAD_MAX_LAYERS];
+    float* in_proj_b[2][IEFVAD_MAX_LAYERS];
+    float* out_proj_w[2][IEFVAD_MAX_LAYERS];
+    float* out_proj_b[2][IEFVAD_MAX_LAYERS];
+    float* norm_w[2][IEFVAD_MAX_LAYERS];
+    float* norm_b[2][IEFVAD_MAX_LAYERS];
+    float* whiten_w[2];
+    float* whiten_b[2];
+    float* mu_w[2];
+    float* mu_b[2];
+    float* logvar_w[2];
+    float* logvar_b[2];
+    float* ref_w1[IEFVAD_MAX_STEPS];
+    float* ref_b1[IEFVAD_MAX_STEPS];
+    float* ref_w2[IEFVAD_MAX_STEPS];
+    float* ref_b2[IEFVAD_MAX_STEPS];
+    float* cls_w;
+    float* cls_b;
+} iefvad_weight_grads;
+
+size_t iefvad_train_workspace_bytes(const iefvad_handle* h, int32_t B);
+int iefvad_train_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
+                         const iefvad_train_options* opt, void* train_ws, size_t train_ws_bytes, const iefvad_outputs* out,
+                         void* stream);
+int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws, size_t train_ws_bytes, const iefvad_output_grads* dout,
+                          const iefvad_weight_grads* dw, void* stream);
 
 /* One torch.optim.AdamW step (as /root/reference/train/ucf_train.py:28 constructs it: betas (0.9, 0.999), eps 1e-8, weight_decay
- * 0.01, amsgrad off) on one flat fp32 tensor, in place, in torch's operation order; `step` counts from 1 (bias corrections are
- * taken on the host in double, as torch takes them in Python floats).  All pointers are device pointers of n floats. */
-int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                      float beta2, float eps, float weight_decay, int32_t step, void* stream);
+ * 0.01, amsgrad off) on one flat fp32 tensor, in place, in torch's operation order; `step` counts from 1.  The hyper-parameters
+ * travel as doubles: torch forms 1 - lr wd, 1 - beta1, 1 - beta2, lr / (1 - beta1^t) and sqrt(1 - beta2^t) in Python floats
+ * and rounds each to fp32 once; so does this.  All pointers are device pointers of n floats. */
+int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, int32_t step, void* stream);
 
 /* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
  * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a

@@ -333,7 +333,144 @@ def gen_loss_grad_case():
     print("wrote", path, os.path.getsize(path), "bytes;", float(store["seed1_total"]), np.abs(store["seed1_image_mu_zero_row"]).max())
 
 
+# (name, weight seed, batch seed, B, L, K, noise, nu, lambda_reg, lambda_kl, dropout p with an injected mask (0 = no dropout))
+GRAD_CASES = [
+    ("k2_student8", 31, 41, 3, 2, 2, "StudentT", 8, 1.0, 1.0, 0.0),
+    ("k10_student8_mask", 32, 42, 2, 2, 10, "StudentT", 8, 1.0, 1.0, 0.1),
+    ("k0_gauss_l1", 33, 43, 2, 1, 0, "Gaussian", 8, 0.01, 0.01, 0.0),
+]
+GRAD_SAMPLES = 192
+
+
+def _reference_train_model(wseed, L, K, noise, nu, dtype, p, mask):
+    """The reference MMFMIL in train() mode with seeded weights.  Attention dropout: every nn.MultiheadAttention's `.dropout` is
+    set to `p`; for p > 0 torch.nn.functional.dropout is replaced, for the duration of the caller's forward, by a function that
+    applies the NEXT injected keep mask exactly as F.dropout applies its own (x * mask / (1 - p)) -- so the reference and the
+    build see the same mask.  Returns (model, context manager)."""
+    import contextlib
+    import torch.nn.functional as F
+    model = build_reference(wseed, L, K, 0.5, noise, nu)
+    model = model.to(dtype)
+    model.train()
+    for mod in list(model.temporal.image_attn_layers) + list(model.temporal.event_attn_layers):
+        mod.dropout = float(p)
+
+    @contextlib.contextmanager
+    def inject():
+        if p <= 0:
+            yield
+            return
+        # forward order of imf_vad.py:113-123: image layers 0..L-1, then event layers 0..L-1; mask is [2, L, B, H, T, T]
+        queue = [torch.from_numpy(mask[m, l]).reshape(-1, 256, 256).to(dtype) for m in range(2) for l in range(L)]
+        orig = F.dropout
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            keep = queue.pop(0)
+            assert keep.shape == x.shape
+            return x * keep * (1.0 / (1.0 - p))
+
+        F.dropout = fake
+        try:
+            yield
+            assert not queue, "every injected mask must have been consumed"
+        finally:
+            F.dropout = orig
+    return model, inject
+
+
+def _trainer_loss(outputs, labels, lengths, noise, nu, lam_reg, lam_kl, CLAS2):
+    """The total the trainers form (/root/reference/train/ucf_train.py:68-102, xd_train.py:54-75), with the reference's own CLAS2."""
+    import math
+    import torch.nn.functional as F
+    image_mu, event_mu = outputs["image_mu"], outputs["event_mu"]
+    cls = CLAS2(outputs["logits"], labels, lengths, "cpu")
+    cos_sim = F.cosine_similarity(F.normalize(image_mu, p=2, dim=-1), F.normalize(event_mu, p=2, dim=-1), dim=-1)
+    loss_reg = (1 - cos_sim).mean() + torch.abs(torch.norm(image_mu, p=2, dim=-1) - torch.norm(event_mu, p=2, dim=-1)).mean()
+    sh = math.log(nu / (nu + 1)) if noise == "StudentT" else 0.0
+    kl = 0.0
+    for mu, lv in ((image_mu, outputs["image_logvar"]), (event_mu, outputs["event_logvar"])):
+        e = lv + sh
+        kl = kl + (-0.5 * torch.mean(1 + e - mu.pow(2) - e.exp()))
+    return cls + lam_reg * loss_reg + lam_kl * kl
+
+
+def gen_model_grad_cases():
+    """f-4, the model's backward pass: the REFERENCE model in train() mode (fp64 copy), the reference's own CLAS2 and the trainers'
+    torch calls, `loss.backward()` -- every parameter gradient of SURVEY.md Appendix B.  Stored per parameter: its L1 and L2
+    norms and GRAD_SAMPLES seeded entries; plus the total loss and the logits (forward check of the train-mode path)."""
+    sys.path.insert(0, REF)
+    from train.loss import CLAS2
+    for name, wseed, bseed, B, L, K, noise, nu, lam_reg, lam_kl, p in GRAD_CASES:
+        mask = synth.make_dropout_mask(bseed, L, B, p) if p > 0 else None
+        model, inject = _reference_train_model(wseed, L, K, noise, nu, torch.float64, p, mask)
+        img, ev, labels, lengths = synth.make_train_batch(bseed, B)
+        with inject():
+            # MMFMIL.forward (imf_vad.py:40-44) is `.to(torch.float)` + this call; entering one level below keeps the graph in fp64
+            out = model.temporal(torch.from_numpy(img).double(), torch.from_numpy(ev).double())
+        total = _trainer_loss(out, torch.from_numpy(labels).double(), torch.from_numpy(lengths), noise, nu, lam_reg, lam_kl, CLAS2)
+        total.backward()
+        store = {"cfg": np.array([wseed, bseed, B, L, K, nu]), "noise": np.array(noise), "lams": np.array([lam_reg, lam_kl]),
+                 "p": np.array(p), "total": np.array(float(total)), "logits": out["logits"].detach().numpy().reshape(B, 256)}
+        names = []
+        for i, (key, prm) in enumerate(model.named_parameters()):
+            g = prm.grad.numpy().reshape(-1)
+            rng = np.random.default_rng([bseed, 900 + i])
+            idx = np.sort(rng.choice(g.size, min(g.size, GRAD_SAMPLES), replace=False))
+            names.append(key)
+            store[f"g{i}_idx"] = idx.astype(np.int64)
+            store[f"g{i}_val"] = g[idx]
+            store[f"g{i}_norms"] = np.array([np.abs(g).sum(), np.sqrt((g * g).sum()), np.abs(g).max()])
+        store["names"] = np.array(names)
+        path = os.path.join(HERE, f"grad_{name}.npz")
+        np.savez_compressed(path, **store)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB; total", float(total), "params", len(names))
+
+
+STEP_CASE = ("k3_student8", 34, 44, 4, 2, 3, "StudentT", 8, 1.0, 1.0, 2)       # ... , optimiser steps
+
+
+def gen_train_step_case():
+    """One (and a second) whole step of /root/reference/train/ucf_train.py:60-106 by the reference in its own arithmetic (fp32):
+    model.train() with the attention dropout at 0, forward, CLAS2 + regulariser + KL, loss.backward(),
+    torch.optim.AdamW(model.parameters(), lr=2e-5).step() (main.py:69's default lr, the trainers' AdamW defaults).  Stored:
+    the losses, and GRAD_SAMPLES seeded entries of every parameter after each step."""
+    sys.path.insert(0, REF)
+    from train.loss import CLAS2
+    name, wseed, bseed, B, L, K, noise, nu, lam_reg, lam_kl, nsteps = STEP_CASE
+    model, inject = _reference_train_model(wseed, L, K, noise, nu, torch.float32, 0.0, None)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-5)
+    store = {"cfg": np.array([wseed, bseed, B, L, K, nu, nsteps]), "noise": np.array(noise), "lams": np.array([lam_reg, lam_kl]),
+             "lr": np.array(2e-5)}
+    losses = []
+    for step in range(nsteps):
+        img, ev, labels, lengths = synth.make_train_batch(bseed + step, B)
+        out = model(torch.from_numpy(img), torch.from_numpy(ev), None, None, torch.from_numpy(lengths))
+        total = _trainer_loss(out, torch.from_numpy(labels), torch.from_numpy(lengths), noise, nu, lam_reg, lam_kl, CLAS2)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        losses.append(float(total))
+        for i, (key, prm) in enumerate(model.named_parameters()):
+            v = prm.detach().numpy().reshape(-1)
+            rng = np.random.default_rng([bseed, 700 + i])
+            idx = np.sort(rng.choice(v.size, min(v.size, GRAD_SAMPLES), replace=False))
+            if step == 0:
+                store[f"p{i}_idx"] = idx.astype(np.int64)
+            store[f"p{i}_step{step}"] = v[idx].copy()
+    store["names"] = np.array([k for k, _ in model.named_parameters()])
+    store["losses"] = np.array(losses)
+    path = os.path.join(HERE, f"train_step_{name}.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; losses", losses)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "modelgrad":
+        gen_model_grad_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trainstep":
+        gen_train_step_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lossgrad":
         gen_loss_grad_case()
         sys.exit(0)
@@ -361,3 +498,5 @@ if __name__ == "__main__":
     gen_config5_gt()
     gen_loss_case()
     gen_loss_grad_case()
+    gen_model_grad_cases()
+    gen_train_step_case()
