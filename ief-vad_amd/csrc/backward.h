@@ -52,31 +52,31 @@ struct BgemmArgs {
 template <bool KC, int ROWS>
 struct BgemmTile {                      // staging of one operand tile: ROWS (i or j) x 16 (k)
     static constexpr int PITCH = KC ? ROWS + 2 : ROWS + 4;
-    static constexpr int NV = KC ? (ROWS * 4 + 255) / 256 : (16 * (ROWS / 4) + 255) / 256;    // float4 per thread
+    static constexpr int NQ = ROWS * 4;                               // 16-byte pieces of the tile
+    static constexpr int NV = (NQ + 255) / 256;                       // per thread
+    // A 96-row tile has 384 pieces for 256 threads: the surplus threads of the second round repeat the LAST piece (same load, same
+    // value to the same LDS address) instead of being masked off -- a masked load would cost the prefetch its asynchrony (the
+    // compiler waits for it on the spot to merge it with the old register value)
+    static __device__ __forceinline__ int piece(int t, int u) { const int idx = t + 256 * u; return idx < NQ ? idx : NQ - 1; }
     // global -> registers
     static __device__ __forceinline__ void load(const float* base, int ld, int k0, f32x4 (&r)[NV], int t) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = t + 256 * u;
-            if (KC) {
-                if (idx < ROWS * 4) r[u] = *(const f32x4*)(base + (size_t)(idx >> 2) * ld + k0 + 4 * (idx & 3));
-            } else {
-                if (idx < 16 * (ROWS / 4)) r[u] = *(const f32x4*)(base + (size_t)(k0 + idx / (ROWS / 4)) * ld + 4 * (idx % (ROWS / 4)));
-            }
+            const int idx = piece(t, u);
+            if (KC) r[u] = *(const f32x4*)(base + (size_t)(idx >> 2) * ld + k0 + 4 * (idx & 3));
+            else r[u] = *(const f32x4*)(base + (size_t)(k0 + idx / (ROWS / 4)) * ld + 4 * (idx % (ROWS / 4)));
         }
     }
     // registers -> LDS image [k][i]
     static __device__ __forceinline__ void store(float* s, const f32x4 (&r)[NV], int t) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int idx = t + 256 * u;
+            const int idx = piece(t, u);
             if (KC) {
-                if (idx < ROWS * 4) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[(4 * (idx & 3) + e) * PITCH + (idx >> 2)] = r[u][e];
-                }
+                for (int e = 0; e < 4; ++e) s[(4 * (idx & 3) + e) * PITCH + (idx >> 2)] = r[u][e];
             } else {
-                if (idx < 16 * (ROWS / 4)) *(f32x4*)(s + (idx / (ROWS / 4)) * PITCH + 4 * (idx % (ROWS / 4))) = r[u];
+                *(f32x4*)(s + (idx / (ROWS / 4)) * PITCH + 4 * (idx % (ROWS / 4))) = r[u];
             }
         }
     }
@@ -91,10 +91,15 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
     constexpr int ASZ = BG_BK * TA::PITCH, BSZ = BG_BK * TB::PITCH;      // buffer c: A at c * ASZ, B at 2 * ASZ + c * BSZ
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, i = lane & 31, h = lane >> 5;
+    // one-dimensional grid over (batch z, tile), walked XCD by XCD: each XCD owns a contiguous range of (z, tile) pairs, so the
+    // tiles that share operand panels (the 6 column tiles of a row block; all 36 tiles of a split-K slice) meet in one L2
     const int ntn = a.N / BN;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int tiles = (a.M / BG_BM) * ntn;
+    const int rid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = rid / tiles, tid = rid - z * tiles;
+    const int tm = tid / ntn, tn = tid - tm * ntn;
     const int m0 = tm * BG_BM, n0 = tn * BN;
-    const int z1 = blockIdx.z / a.nz2, z2 = blockIdx.z - z1 * a.nz2;
+    const int z1 = z / a.nz2, z2 = z - z1 * a.nz2;
     const float* Ab = a.A + z1 * a.a1 + z2 * a.a2 + (A_KC ? (size_t)m0 * a.lda : (size_t)m0);
     const float* Bb = a.B + z1 * a.b1 + z2 * a.b2 + (B_KC ? (size_t)n0 * a.ldb : (size_t)n0);
     const size_t coff = (size_t)(z1 * a.c1 + z2 * a.c2);
@@ -121,14 +126,23 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
         }
         const float* ap = smem + cur * ASZ + h * TA::PITCH + 32 * w + i;
         const float* bp = smem + 2 * ASZ + cur * BSZ + h * TB::PITCH + i;
+        // fragments of k-step s + 1 are requested before the MFMAs of k-step s (pinned: hipcc otherwise sinks every read to
+        // its first use and the wave waits out an LDS round trip per pair of MFMAs)
+        float av[2], bv[2][NT];
+        av[0] = ap[0];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[0][b] = bp[32 * b];
 #pragma unroll
         for (int s = 0; s < BG_BK / 2; ++s) {
-            const float av = ap[2 * s * TA::PITCH];
-            float bv[NT];
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < BG_BK / 2) {
+                av[n] = ap[2 * (s + 1) * TA::PITCH];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bv[b] = bp[2 * s * TB::PITCH + 32 * b];
+                for (int b = 0; b < NT; ++b) bv[n][b] = bp[2 * (s + 1) * TB::PITCH + 32 * b];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[b], acc[b], 0, 0, 0);
+            for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c][b], acc[b], 0, 0, 0);
         }
         if (more) {
             TA::store(smem + (cur ^ 1) * ASZ, ra, t);
@@ -244,13 +258,45 @@ __global__ __launch_bounds__(256) void iefvad_colsum_kernel(const float* Y, int 
     part[(size_t)blockIdx.y * ncols + j] = (s0 + s1) + (s2 + s3);
 }
 
-// out[i] = alpha * (part[0][i] + part[1][i] + ...), in index order
+// out[i] = alpha * sum_p part[p][i] in a FIXED order: the partials are cut into 16 contiguous groups, thread (group g, column
+// quad c) adds its group's partials of four consecutive elements in index order (eight loads in flight), and the 16 group sums
+// are added in group order through LDS.  One workgroup per 64-element strip: a 1024-partial LayerNorm reduction is 64 dependent
+// steps per thread instead of 1024, a 32-way split-K reduction streams with every thread loading.
+#define RED_STRIP 64
 __global__ __launch_bounds__(256) void iefvad_reduce_parts_kernel(const float* part, size_t stride, int nparts, size_t n, float* out, float alpha) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];
-    out[i] = alpha * s;
+    __shared__ __attribute__((aligned(16))) float sm[16][RED_STRIP];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * RED_STRIP + 4 * c;
+    const int chunk = (nparts + 15) / 16;
+    const int p0 = g * chunk, p1 = (p0 + chunk < nparts) ? p0 + chunk : nparts;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i + 4 <= n && !(stride & 3) && !((uintptr_t)part & 15)) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(part + (size_t)(p + u) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < p1; ++p) s += *(const f32x4*)(part + (size_t)p * stride + i);
+    } else {
+        for (int p = p0; p < p1; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < n) s[e] += part[(size_t)p * stride + i + e];
+    }
+    *(f32x4*)&sm[g][4 * c] = s;
+    __syncthreads();
+    if (threadIdx.x < RED_STRIP) {
+        const size_t j = (size_t)blockIdx.x * RED_STRIP + threadIdx.x;
+        if (j < n) {
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r += sm[q][threadIdx.x];
+            out[j] = alpha * r;
+        }
+    }
 }
 
 // the 4 waves' per-lane column partials (lane l owns columns 4 l + 256 j) -> part[block][768], waves added in order

@@ -99,7 +99,7 @@ static int launch_bgemm(const BgemmArgs& a, bool akc, bool bkc, int nz, hipStrea
     if (a.M % BG_BM || a.N % bn || a.K % BG_BK || a.M <= 0 || a.N <= 0 || a.K <= 0 || nz <= 0 || a.nz2 <= 0)
         return fail("bgemm: shape M=%d N=%d K=%d is not a multiple of the 128 x %d x 16 tile", a.M, a.N, a.K, bn);
     if ((a.lda | a.ldb) & 3) return fail("bgemm: leading dimensions must be multiples of 4 floats");
-    dim3 grid((a.M / BG_BM) * (a.N / bn), 1, nz);
+    dim3 grid((unsigned)((a.M / BG_BM) * (a.N / bn) * nz));
 #define BG_LAUNCH(AK, BK_, BN_) hipLaunchKernelGGL((iefvad_bgemm_f32_kernel<AK, BK_, BN_>), grid, dim3(256), 0, stream, a)
     if (bn == 128) {
         if (akc && bkc) BG_LAUNCH(true, true, 128);
@@ -145,11 +145,11 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
     if (int rc = launch_bgemm(a, false, false, splits, stream)) return rc;
     if (dW) {
         const size_t n = (size_t)(n_split > 0 ? n_split : n_out) * IEF_D;
-        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, per, splits, n, dW, alpha);
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part, per, splits, n, dW, alpha);
     }
     if (dW2) {
         const size_t n = (size_t)(n_out - n_split) * IEF_D;
-        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
                            per, splits, n, dW2, alpha);
     }
     HIP_TRY(hipGetLastError());
@@ -164,11 +164,11 @@ static int launch_db(const float* Y, int ld, int ncols, float* db, float* db2, i
     hipLaunchKernelGGL(iefvad_colsum_kernel, dim3((ncols + 255) / 256, nblk), dim3(256), 0, stream, Y, ld, rows, ncols, kColsumRows, cpart);
     if (db) {
         const size_t n = n_split > 0 ? n_split : ncols;
-        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cpart, (size_t)ncols, nblk, n, db, alpha);
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart, (size_t)ncols, nblk, n, db, alpha);
     }
     if (db2) {
         const size_t n = ncols - n_split;
-        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cpart + n_split, (size_t)ncols, nblk,
+        hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart + n_split, (size_t)ncols, nblk,
                            n, db2, alpha);
     }
     HIP_TRY(hipGetLastError());
@@ -393,7 +393,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         sa.part_w = rpart; sa.part_b = rpart + (size_t)nblk * IEF_D; sa.rows = rows;
         hipLaunchKernelGGL(iefvad_scorer_bwd_kernel, dim3(nblk), dim3(256), 0, stream, sa);
         if (dw->cls_w)
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dw->cls_w, 1.f);
+            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dw->cls_w, 1.f);
         if (dw->cls_b)
             hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(1), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)1, nblk, (size_t)1,
                                dw->cls_b, 1.f);
@@ -438,9 +438,9 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             la.x = x; la.dy = gx; la.g = gamma; la.dx = gx; la.part_g = rpart; la.part_b = rpart + (size_t)nblk * IEF_D; la.rows = rows; la.eps = 1e-5f;
             hipLaunchKernelGGL(iefvad_layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, stream, la);
             if (dgamma)
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dgamma, 1.f);
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dgamma, 1.f);
             if (dbeta)
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(3), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)IEF_D, nblk,
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)IEF_D, nblk,
                                    (size_t)IEF_D, dbeta, 1.f);
             HIP_TRY(hipGetLastError());
             return 0;
