@@ -34,6 +34,7 @@ The JSON line also carries
   xd_eval, shang_msad_eval   BASELINE configs 3 and 5 (XD-Violence-sized; ShanghaiTech + MSAD sized with K = 5), bf16 projections
                 with fp32 state, packed evaluation loop: snippets/s, AUC / AP, and their distance from the fp32 CPU oracle on a
                 bounded prefix of the list.
+  train_step    SURVEY 8f-4: whole training steps (train-mode forward, loss, backward, AdamW) at the reference's UCF batch size.
   ucf_eval      BASELINE config 2 (UCF-Crime-sized synthetic set, 290 videos, ~69.5 k snippets) through harness.test:
                 the reference's per-video call pattern and the cross-video batched pattern, snippets/s wall clock
                 including H2D, |dAUC| against the CPU oracle on a bounded sample, and the oracle's own rate.
@@ -411,6 +412,42 @@ def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=
     return out
 
 
+def train_step_block(dev, a, chunks=128, steps=4):
+    """whole training steps of the reference's UCF configuration (train/ucf_train.py:43-106 with main.py's defaults:
+    2 x batch_size 64 = 128 chunks of [256, 768], K = 10, StudentT nu = 8, attention dropout 0.1, AdamW lr 2e-5) on this GPU:
+    train-mode forward, CLAS2 + regulariser + KL, backward of the loss head and of the model, AdamW -- all in libiefvad (fp32 MFMA).
+    Algorithmic FLOPs per step = 3 x the forward's 50.33 MFLOP per snippet."""
+    import torch
+    import iefvad_amd
+    from iefvad_amd import losses, synth, trainer
+    margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K_STEPS, lambda_ref=0.5, noise_model="StudentT", nu=8)
+    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, compute="f32")
+    model.load_state_dict(synth.make_state_dict(0, D, L, K_STEPS))
+    model = model.to(dev).train()
+    opt = losses.AdamW(model.parameters(), lr=2e-5)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    img = torch.randn(chunks, T, D, device=dev, generator=gen) * 0.45
+    ev = torch.randn(chunks, T, D, device=dev, generator=gen) * 0.45
+    labels = torch.zeros(chunks, 14, device=dev)
+    labels[: chunks // 2, 0] = 1
+    labels[chunks // 2:, 3] = 1
+    lengths = torch.full((chunks,), T, dtype=torch.int64, device=dev)
+    for _ in range(2):
+        terms = trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops = 3 * TOTAL_FLOPS_PER_SNIPPET * chunks * T
+    return {"workload": f"training step, {chunks} chunks x {T} x {D} (ucf_train.py: 2 x batch_size 64), K={K_STEPS}, L={L}, StudentT, attention "
+                        f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute=f32",
+            "snippets_per_s": chunks * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_tflop_per_step": flops / 1e12,
+            "achieved_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "loss_total": float(terms["total"])}
+
+
 def xd_parts():
     from iefvad_amd import harness, synth
     lengths = synth.lognormal_lengths(2, 753, 145000)
@@ -604,6 +641,7 @@ def main():
                                            batch_chunks=128, lanes=2)
             line["shang_msad_eval"] = dataset_eval("BASELINE config 5 (real gt and label order, synthetic features)", config5_parts(),
                                                    19, 5, "bf16", dev, a, batch_chunks=128, lanes=2)
+            line["train_step"] = train_step_block(dev, a)
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)

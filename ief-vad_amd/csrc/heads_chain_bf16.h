@@ -9,13 +9,12 @@
 //            registers): biases, fuse_elem (rowops.h: the fusion kernel's own operations) and the stores follow in registers,
 //            no LDS park, no partner wave.
 // Weights are read once per 64 rows (4.7 MB over the three column thirds), the same L2 -> CU stream per row as the
-// in_proj kernel's; the 256 x 64 ring kernel (heads_fused_bf16.h) reads 196 KB of A and W per k-tile barrier for the same work.
+// in_proj kernel's; round 2's 256 x 64 ring kernel (tools/heads_fused_bf16_v1.h) read 196 KB of A and W per k-tile barrier for the same work.
 // Same products in the same k order, same epilogue arithmetic: mu, logvar, n_i, n_e and z are bit-identical to
-// heads_fused_bf16.h and to the unfused path; the row sums of n_i / n_e leave as 24 partials per row (32 columns each)
-// instead of 12 and are finished in a fixed order (IEFVAD_HEADS_V1=1 selects the ring kernel for the A/B).
+// the unfused path (heads GEMM + fusion kernel: IEFVAD_ROWBLOCK_OFF=4); the row sums of n_i / n_e leave as 24 partials per row (32
+// columns each) and are finished in a fixed order by iefvad_rowmean_finish_kernel.
 #pragma once
 #include "outproj_ln_chain_bf16.h"
-#include "heads_fused_bf16.h"
 
 #define HC_BM 64
 #define HC_THIRDS 3
@@ -205,4 +204,21 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_chain_bf16_kernel(HeadsCh
         }
     }
     HC_STAMP(5);
+}
+
+// row means of the normalised weights from the kernel's partial sums: fixed order, one thread per (row, modality) -- its np =
+// HC_NPART floats are contiguous, neighbouring threads read neighbouring 16-byte vectors
+__global__ __launch_bounds__(256) void iefvad_rowmean_finish_kernel(const float* part, float* n_i_mean, float* n_e_mean, int nrows, int np) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int row = id >> 1, mod = id & 1;
+    if (row >= nrows) return;
+    float* dst = mod ? n_e_mean : n_i_mean;
+    if (!dst) return;
+    const float* p = part + ((size_t)row * 2 + mod) * np;
+    float s = 0.f;
+    for (int b = 0; b < np; b += 4) {
+        const f32x4 v = *(const f32x4*)(p + b);
+        s += v[0]; s += v[1]; s += v[2]; s += v[3];
+    }
+    dst[row] = s * (1.0f / IEF_D);
 }

@@ -1,0 +1,387 @@
+// iefvad_forward_videos_host: a whole evaluation list in ONE library call (include/iefvad.h).  Included by iefvad.hip behind
+// forward_videos_impl and stream_copy.
+//
+// The reference's evaluation loop (/root/reference/test.py:76-121; data/dataset.py:34-52) loads, pads, uploads and scores one video
+// per Python iteration.  iefvad_forward_videos already takes only the valid rows of a packed batch of videos, but the loop around it
+// was Python: per batch it built pointer tables, staged the rows into pinned memory, issued the copies and the forward -- on short
+// videos (ShanghaiTech / MSAD: 40 snippets on average) three times the device time.  Here the caller hands over the HOST row
+// pointers and lengths of every video and the library walks the list:
+//   * a worker thread gathers the rows of the next passes into a ring of four pinned staging slots (non-temporal stores, a
+//     persistent pool of copy threads, byte ranges balanced across videos);
+//   * the calling thread sends pass k on an internal copy stream (one asynchronous copy per modality) and enqueues its forward
+//     (forward_videos_impl) behind an event on one of two internal compute streams, alternating: copies run under forwards, and two
+//     partly filled passes run side by side;
+//   * per-snippet results land in the caller's DEVICE vectors in list order; the caller's stream waits for both compute streams at
+//     the end of the call (nothing is read back here).
+// Staging slots, device input slots and the forward's workspace belong to the handle and are reused across calls (pinning memory
+// costs milliseconds per 100 MB).  A slot is rewritten only after the event behind its last use has completed.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
+// A few persistent copy threads: a job is one byte stream (the concatenation of `count` pieces) cut into equal byte ranges, one per
+// thread -- a range may start and end inside a piece, so short and long videos balance.  Threads sleep between jobs.
+struct GatherPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    unsigned long long generation = 0;
+    int pending = 0;
+    bool stop = false;
+    // the job
+    char* dst = nullptr;
+    const void* const* srcs = nullptr;
+    const size_t* offs = nullptr;        // count + 1 prefix sums of the piece sizes
+    int64_t count = 0;
+
+    void work(int t, int nt) {
+        const size_t total = offs[count];
+        const size_t lo = total / nt * t, hi = (t == nt - 1) ? total : total / nt * (t + 1);
+        if (hi <= lo) return;
+        int64_t i = (int64_t)(std::upper_bound(offs, offs + count + 1, lo) - offs) - 1;      // piece that holds byte lo
+        size_t pos = lo;
+        while (pos < hi) {
+            const size_t end = offs[i + 1] < hi ? offs[i + 1] : hi;
+            if (end > pos) stream_copy(dst + pos, (const char*)srcs[i] + (pos - offs[i]), end - pos);
+            pos = end;
+            ++i;
+        }
+        __builtin_ia32_sfence();
+    }
+    void loop(int t) {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            work(t + 1, (int)threads.size() + 1);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    // called by ONE thread at a time; the caller copies range 0 itself
+    void run(char* dst_, const void* const* srcs_, const size_t* offs_, int64_t count_) {
+        dst = dst_; srcs = srcs_; offs = offs_; count = count_;
+        const size_t total = offs_[count_];
+        if (threads.empty() || total < ((size_t)1 << 20)) { work(0, 1); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            pending = (int)threads.size();
+            ++generation;
+        }
+        cv_go.notify_all();
+        work(0, (int)threads.size() + 1);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void start(int n) {
+        try {
+            for (int t = (int)threads.size(); t < n - 1; ++t) threads.emplace_back([this, t] { loop(t); });
+        } catch (...) {}            // fewer threads than asked for: the ranges adapt
+    }
+    ~GatherPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto& th : threads) th.join();
+    }
+};
+
+struct HostPipe {
+    GatherPool* pool = nullptr;
+    hipStream_t copy_stream = nullptr;
+    static const int kSlots = 4;                    // passes in flight: one being gathered, one or two being sent, one being computed
+    void* pinned[kSlots][2] = {};                   // [slot][modality]
+    void* dev_in[kSlots][2] = {};
+    size_t slot_bytes = 0;
+    hipEvent_t sent[kSlots] = {};                   // the copies out of pinned[slot] have completed
+    hipEvent_t used[kSlots] = {};                   // the forward that read dev_in[slot] has completed
+    hipEvent_t ready = nullptr;                     // caller's stream -> internal streams ordering at entry
+    // passes alternate between two compute streams (each with a workspace of its own): the kernels of a 60 - 130 chunk pass fill a
+    // fraction of the chip and are latency-bound one behind the other; two passes side by side overlap (as harness lanes = 2 did)
+    static const int kLanes = 2;
+    hipStream_t lane[kLanes] = {};
+    hipEvent_t lane_done[kLanes] = {};
+    void* workspace[kLanes] = {};
+    size_t workspace_bytes = 0;
+};
+
+static void release_hostpipe(iefvad_handle* h) {
+    HostPipe* p = h->hostpipe;
+    if (!p) return;
+    for (int s = 0; s < HostPipe::kSlots; ++s) {
+        for (int m = 0; m < 2; ++m) {
+            if (p->pinned[s][m]) (void)hipHostFree(p->pinned[s][m]);
+            if (p->dev_in[s][m]) (void)hipFree(p->dev_in[s][m]);
+        }
+        if (p->sent[s]) (void)hipEventDestroy(p->sent[s]);
+        if (p->used[s]) (void)hipEventDestroy(p->used[s]);
+    }
+    if (p->ready) (void)hipEventDestroy(p->ready);
+    for (int l = 0; l < HostPipe::kLanes; ++l) {
+        if (p->workspace[l]) (void)hipFree(p->workspace[l]);
+        if (p->lane[l]) (void)hipStreamDestroy(p->lane[l]);
+        if (p->lane_done[l]) (void)hipEventDestroy(p->lane_done[l]);
+    }
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    delete p->pool;
+    delete p;
+    h->hostpipe = nullptr;
+}
+
+// contiguous-range copy of `count` pieces into dst by up to `threads` threads (the body of iefvad_host_gather)
+static void host_gather_run(char* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int threads) {
+    std::vector<size_t> off((size_t)count + 1);
+    off[0] = 0;
+    for (int64_t i = 0; i < count; ++i) off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
+    const size_t total = off[(size_t)count];
+    int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (total < ((size_t)4 << 20)) nt = 1;
+    auto run = [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i)
+            if (nbytes[i]) stream_copy(dst + off[(size_t)i], (const char*)srcs[i], nbytes[i]);
+        __builtin_ia32_sfence();
+    };
+    if (nt == 1) { run(0, count); return; }
+    std::vector<int64_t> cut((size_t)nt + 1, count);
+    cut[0] = 0;
+    int k = 1;
+    for (int64_t i = 0; i < count && k < nt; ++i)
+        if (off[(size_t)i + 1] >= total / nt * k) cut[(size_t)k++] = i + 1;
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < nt; ++t)
+            if (cut[(size_t)t + 1] > cut[(size_t)t]) pool.emplace_back(run, cut[(size_t)t], cut[(size_t)t + 1]);
+    } catch (...) {
+        for (auto& th : pool) th.join();
+        run(cut[1], count);
+        run(0, cut[1]);
+        return;
+    }
+    run(0, cut[1]);
+    for (auto& th : pool) th.join();
+}
+
+extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, const void* const* ev_rows, int32_t in_dtype,
+                                          const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
+                                          int32_t host_threads, float* logits, float* w_i_mean, float* w_e_mean, void* stream_) {
+    if (!h || !img_rows || !ev_rows || !lengths || !logits) return fail("iefvad_forward_videos_host: null argument");
+    if (!h->weights_set) return fail("iefvad_forward_videos_host: weights not set");
+    if (nvideos <= 0) return fail("iefvad_forward_videos_host: nvideos must be positive (got %d)", nvideos);
+    if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
+        return fail("iefvad_forward_videos_host: unknown in_dtype %d", in_dtype);
+    for (int v = 0; v < nvideos; ++v) {
+        if (lengths[v] <= 0) return fail("iefvad_forward_videos_host: lengths[%d] = %d", v, lengths[v]);
+        if (!img_rows[v] || !ev_rows[v]) return fail("iefvad_forward_videos_host: null row pointer (video %d)", v);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t esz = in_elem_bytes(in_dtype), row_bytes = (size_t)IEF_D * esz;
+    const int want = batch_chunks > 0 ? batch_chunks : 128;
+    try {
+
+    // passes: runs of whole videos with >= `want` chunks; the FIRST pass is half that (the first forward starts after a short
+    // gather + copy) and the last chunks of the list are cut into two halves (what is left when the call returns is the copy
+    // and the forward of a half pass).  Finer tapering loses: every pass costs ~0.3 ms of copy / event latency.
+    struct Batch { int v0, v1; long long rows, chunks; };
+    std::vector<Batch> batches;
+    long long max_rows = 0, max_chunks = 0, total_chunks = 0;
+    for (int v = 0; v < nvideos; ++v) total_chunks += video_chunks(lengths[v]);
+    {
+        Batch b = {0, 0, 0, 0};
+        long long done_chunks = 0;
+        long long target = want / 2 > 16 ? want / 2 : want;
+        for (int v = 0; v < nvideos; ++v) {
+            b.rows += lengths[v];
+            b.chunks += video_chunks(lengths[v]);
+            b.v1 = v + 1;
+            if (b.chunks >= target || v == nvideos - 1) {
+                batches.push_back(b);
+                if (b.rows > max_rows) max_rows = b.rows;
+                if (b.chunks > max_chunks) max_chunks = b.chunks;
+                done_chunks += b.chunks;
+                b = Batch{v + 1, v + 1, 0, 0};
+                const long long left = total_chunks - done_chunks;
+                target = want;
+                if (left < want + want / 2 && left > want / 2) target = (left + 1) / 2;
+            }
+        }
+    }
+    if (max_chunks > 0x7fffffffLL / IEF_T) return fail("iefvad_forward_videos_host: batch too large");
+
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->hostpipe) {
+        h->hostpipe = new (std::nothrow) HostPipe();
+        if (!h->hostpipe) return fail("iefvad_forward_videos_host: out of host memory");
+        HostPipe& p = *h->hostpipe;
+        HIP_TRY(hipStreamCreateWithFlags(&p.copy_stream, hipStreamNonBlocking));
+        for (int s = 0; s < HostPipe::kSlots; ++s) {
+            HIP_TRY(hipEventCreateWithFlags(&p.sent[s], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p.used[s], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
+        for (int l = 0; l < HostPipe::kLanes; ++l) {
+            HIP_TRY(hipStreamCreateWithFlags(&p.lane[l], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&p.lane_done[l], hipEventDisableTiming));
+        }
+    }
+    HostPipe& p = *h->hostpipe;
+    const size_t need_slot = (size_t)max_rows * row_bytes;
+    if (p.slot_bytes < need_slot) {
+        for (int s = 0; s < HostPipe::kSlots; ++s) {       // nothing may still be reading the old slots
+            HIP_TRY(hipEventSynchronize(p.sent[s]));
+            HIP_TRY(hipEventSynchronize(p.used[s]));
+            for (int m = 0; m < 2; ++m) {
+                if (p.pinned[s][m]) (void)hipHostFree(p.pinned[s][m]);
+                if (p.dev_in[s][m]) (void)hipFree(p.dev_in[s][m]);
+                p.pinned[s][m] = p.dev_in[s][m] = nullptr;
+            }
+        }
+        p.slot_bytes = 0;
+        const size_t cap = need_slot + need_slot / 4 + 4096;
+        for (int s = 0; s < HostPipe::kSlots; ++s)
+            for (int m = 0; m < 2; ++m) {
+                HIP_TRY(hipHostMalloc(&p.pinned[s][m], cap, hipHostMallocDefault));
+                HIP_TRY(hipMalloc(&p.dev_in[s][m], cap));
+            }
+        p.slot_bytes = cap;
+    }
+    const size_t need_ws = iefvad_workspace_bytes(h, (int32_t)max_chunks);
+    if (p.workspace_bytes < need_ws) {
+        HIP_TRY(hipDeviceSynchronize());                   // a forward of an earlier call may still use the old workspaces
+        p.workspace_bytes = 0;
+        for (int l = 0; l < HostPipe::kLanes; ++l) {
+            if (p.workspace[l]) (void)hipFree(p.workspace[l]);
+            p.workspace[l] = nullptr;
+            HIP_TRY(hipMalloc(&p.workspace[l], need_ws + need_ws / 8));
+        }
+        p.workspace_bytes = need_ws + need_ws / 8;
+    }
+
+    // ---- worker: stage batch k into pinned slot k % 2 as soon as the copies of batch k - 2 have left it
+    const int nb = (int)batches.size();
+    std::mutex mu;
+    std::condition_variable cv;
+    int staged = 0;                 // batches whose rows are in pinned memory
+    int issued = 0;                 // batches whose copies have been enqueued (their `sent` event recorded)
+    bool abort_all = false;
+    const int nthreads = host_threads > 0 ? (host_threads > 16 ? 16 : host_threads) : 8;
+    if (!p.pool) p.pool = new (std::nothrow) GatherPool();
+    if (!p.pool) return fail("iefvad_forward_videos_host: out of host memory");
+    p.pool->start(nthreads);
+    std::vector<const void*> srcs;
+    std::vector<size_t> offs;
+    srcs.reserve((size_t)nvideos);
+    offs.reserve((size_t)nvideos + 1);
+    auto stage = [&](int k) {       // the slot is free: gather the rows of batch k into it
+        const int s = k % HostPipe::kSlots;
+        (void)hipEventSynchronize(p.sent[s]);
+        const Batch& b = batches[(size_t)k];
+        const int n = b.v1 - b.v0;
+        srcs.resize((size_t)n);
+        offs.resize((size_t)n + 1);
+        offs[0] = 0;
+        for (int i = 0; i < n; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + (size_t)lengths[b.v0 + i] * row_bytes;
+        for (int m = 0; m < 2; ++m) {
+            for (int i = 0; i < n; ++i) srcs[(size_t)i] = (m ? ev_rows : img_rows)[b.v0 + i];
+            p.pool->run((char*)p.pinned[s][m], srcs.data(), offs.data(), n);
+        }
+    };
+    std::thread worker;
+    bool threaded = nb > 1;
+    if (threaded) {
+        try {
+            worker = std::thread([&] {
+                for (int k = 0; k < nb; ++k) {
+                    {   // the slot was last used by pass k - kSlots: its `sent` event must have been RECORDED (issued > k - kSlots)
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return abort_all || issued > k - HostPipe::kSlots; });
+                        if (abort_all) return;
+                    }
+                    stage(k);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        staged = k + 1;
+                    }
+                    cv.notify_all();
+                }
+            });
+        } catch (...) {
+            threaded = false;       // thread creation refused: stage inline, batch by batch
+        }
+    }
+
+    // ---- this thread: copies on the copy stream, forwards on the caller's stream
+    int rc = 0;
+    hipError_t he = hipEventRecord(p.ready, stream);             // inputs of this call must not overtake what the caller enqueued before
+    if (he == hipSuccess) he = hipStreamWaitEvent(p.copy_stream, p.ready, 0);
+    for (int l = 0; l < HostPipe::kLanes && he == hipSuccess; ++l) he = hipStreamWaitEvent(p.lane[l], p.ready, 0);
+    long long row0 = 0;
+    Timer tm;
+    static const bool trace = [] { const char* v = getenv("IEFVAD_HOSTPIPE_TRACE"); return v && v[0] == '1'; }();
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = trace ? now_us() : 0.0;
+    for (int k = 0; k < nb && rc == 0 && he == hipSuccess; ++k) {
+        const int s = k % HostPipe::kSlots;
+        const Batch& b = batches[(size_t)k];
+        const double t0 = trace ? now_us() : 0.0;
+        if (threaded) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return staged > k; });
+        } else {
+            stage(k);
+        }
+        const double t1 = trace ? now_us() : 0.0;
+        const size_t bytes = (size_t)b.rows * row_bytes;
+        he = hipStreamWaitEvent(p.copy_stream, p.used[s], 0);    // the forward of batch k - 2 has read dev_in[s]
+        for (int m = 0; m < 2 && he == hipSuccess; ++m)
+            he = hipMemcpyAsync(p.dev_in[s][m], p.pinned[s][m], bytes, hipMemcpyHostToDevice, p.copy_stream);
+        if (he == hipSuccess) he = hipEventRecord(p.sent[s], p.copy_stream);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            issued = k + 1;
+        }
+        cv.notify_all();
+        if (he != hipSuccess) break;
+        // fp16x3 keeps its running-max words on the handle: one pass at a time there
+        const int ln = h->cfg.compute == IEFVAD_COMPUTE_FP16X3 ? 0 : k % HostPipe::kLanes;
+        hipStream_t cs = p.lane[ln];
+        he = hipStreamWaitEvent(cs, p.sent[s], 0);
+        if (he != hipSuccess) break;
+        rc = forward_videos_impl(h, p.dev_in[s][0], p.dev_in[s][1], in_dtype, lengths + b.v0, b.v1 - b.v0, nan_to_num,
+                                 p.workspace[ln], p.workspace_bytes, logits + row0, w_i_mean ? w_i_mean + row0 : nullptr,
+                                 w_e_mean ? w_e_mean + row0 : nullptr, cs, tm);
+        if (rc == 0) he = hipEventRecord(p.used[s], cs);
+        if (trace)
+            fprintf(stderr, "[hostpipe] pass %d: %lld chunks %lld rows | waited for staging %.0f us | enqueue copies + forward %.0f us | t = %.0f us\n", k,
+                    b.chunks, b.rows, t1 - t0, now_us() - t1, now_us() - t_begin);
+        row0 += b.rows;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != 0 || he != hipSuccess) abort_all = true;
+        issued = nb + HostPipe::kSlots;
+    }
+    cv.notify_all();
+    if (worker.joinable()) worker.join();
+    // the caller's stream continues behind both lanes
+    for (int l = 0; l < HostPipe::kLanes; ++l) {
+        hipError_t e2 = hipEventRecord(p.lane_done[l], p.lane[l]);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(stream, p.lane_done[l], 0);
+        if (he == hipSuccess) he = e2;
+    }
+    if (rc) return rc;
+    if (he != hipSuccess) return fail("iefvad_forward_videos_host: %s", hipGetErrorString(he));
+    return 0;
+    } catch (const std::exception& e) {      // nothing throws across the ABI (allocation failures of the host-side tables)
+        return fail("iefvad_forward_videos_host: %s", e.what());
+    }
+}

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <exception>
 #include <new>
 #include <thread>
 #include <vector>
@@ -23,8 +24,6 @@
 #include "gemm_bf16.h"
 #include "gemm_split.h"
 #include "rowops.h"
-#include "heads_fused_bf16.h"
-#include "outproj_ln_bf16.h"
 #include "refine_chain_bf16.h"
 #include "outproj_ln_chain_bf16.h"
 #include "inproj_chain_bf16.h"
@@ -60,18 +59,18 @@ struct iefvad_handle {
     iefvad_config cfg;
     int device;
     bool weights_set;
-    bool no_heads_fusion;  // IEFVAD_NO_HEADS_FUSION=1 at iefvad_create: bf16 mode runs heads and fusion as two kernels (A/B, tests)
-    bool no_ln_fusion;     // IEFVAD_NO_LN_FUSION=1: bf16 mode runs out_proj and LayerNorm as two kernels
-    bool ol_v1;            // IEFVAD_OL_V1=1: bf16 mode's fused out_proj + LayerNorm on the first design (outproj_ln_bf16.h) instead of the chain-style one
+    // IEFVAD_ROWBLOCK_OFF=<mask> at iefvad_create (A/B runs and the bit-identity tests): bf16 mode takes the stage off its row-block kernel
+    //   1 in_proj -> ring GEMM (+ the stand-alone cast); 2 out_proj + LayerNorm -> ring GEMM + LayerNorm kernel;
+    //   4 heads + fusion -> ring GEMM + fusion kernel; 8 refinement chain -> 2K projection launches + the scorer kernel
+    bool no_heads_fusion, no_ln_fusion;
     char* iproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: in_proj weights in per-wave fragment order, q | k | v passes (inproj_chain_bf16.h)
     char* heads_stream;    // bf16 mode: the four head matrices in per-wave fragment order (heads_chain_bf16.h)
-    bool heads_v1;         // IEFVAD_HEADS_V1=1: bf16 mode's fused heads + fusion on the 256 x 64 ring kernel (heads_fused_bf16.h)
     int chain_min_blocks;  // bf16 mode: the refinement chain kernel takes a micro-batch from this many 64-row blocks on (IEFVAD_CHAIN_MIN_BLOCKS overrides)
     int rowblock_min_wgs;  // bf16 mode: the row-block kernels take a projection from this many workgroups on (IEFVAD_ROWBLOCK_MIN_WGS overrides)
-    bool no_inproj_chain;  // IEFVAD_NO_INPROJ_CHAIN=1: bf16 mode's in_proj on the 256 x 256 ring kernel (and the stand-alone cast in front of it)
+    bool no_inproj_chain;
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
     bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
-    bool no_chain;         // IEFVAD_NO_CHAIN=1: bf16 mode runs the refinement as 2K projection launches + the scorer kernel
+    bool no_chain;
     char* chain_stream;    // bf16 mode: the refinement weights in the chain kernel's per-wave piece order (refine_chain_bf16.h)
     float* arena;          // one allocation holding every repacked weight
     size_t arena_floats;
@@ -118,6 +117,7 @@ struct iefvad_handle {
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
     struct MetaRing* meta;      // pinned / device metadata buffers of iefvad_forward_videos
+    struct HostPipe* hostpipe;  // staging slots, copy stream and workspace of iefvad_forward_videos_host (hostpipe.h)
     struct TrainState* train;   // records of the train-mode forwards whose backward is outstanding (train.h)
 };
 static const int kAmaxActBase = 256;   // running-max slots of the projection matrices (multi-way words); behind them the activations'
@@ -167,13 +167,12 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (!h) return fail("iefvad_create: out of host memory");
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
-    { const char* v = getenv("IEFVAD_NO_HEADS_FUSION"); h->no_heads_fusion = v && v[0] == '1'; }
-    { const char* v = getenv("IEFVAD_NO_LN_FUSION"); h->no_ln_fusion = v && v[0] == '1'; }
-    { const char* v = getenv("IEFVAD_NO_CHAIN"); h->no_chain = v && v[0] == '1'; }
-    { const char* v = getenv("IEFVAD_OL_V1"); h->ol_v1 = v && v[0] == '1'; }
+    {
+        const char* v = getenv("IEFVAD_ROWBLOCK_OFF");
+        const int off = v ? atoi(v) : 0;
+        h->no_inproj_chain = off & 1; h->no_ln_fusion = off & 2; h->no_heads_fusion = off & 4; h->no_chain = off & 8;
+    }
     { const char* v = getenv("IEFVAD_DENSE_ENCODER"); h->dense_encoder = v && v[0] == '1'; }
-    { const char* v = getenv("IEFVAD_NO_INPROJ_CHAIN"); h->no_inproj_chain = v && v[0] == '1'; }
-    { const char* v = getenv("IEFVAD_HEADS_V1"); h->heads_v1 = v && v[0] == '1'; }
     { const char* v = getenv("IEFVAD_ROWBLOCK_MIN_WGS"); h->rowblock_min_wgs = (v && atoi(v) > 0) ? atoi(v) : 128; }      // tools/rowblock_threshold_probe.py
     { const char* v = getenv("IEFVAD_CHAIN_MIN_BLOCKS"); h->chain_min_blocks = (v && atoi(v) > 0) ? atoi(v) : 4; }         // one chunk: 4 blocks take one block time, 2K launches more
     hipError_t e = hipGetDevice(&h->device);
@@ -186,12 +185,6 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB3_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)iefvad_heads_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                HF_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                OL_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_refine_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RC_LDS_BYTES);
@@ -238,6 +231,7 @@ static void release_events(iefvad_handle* h);
 static void release_graphs(iefvad_handle* h);
 static void release_meta(iefvad_handle* h);
 static void release_train(iefvad_handle* h);
+static void release_hostpipe(iefvad_handle* h);
 
 extern "C" void iefvad_destroy(iefvad_handle* h) {
     if (!h) return;
@@ -257,6 +251,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     release_graphs(h);
     release_meta(h);
     release_train(h);
+    release_hostpipe(h);
     delete h;
 }
 
@@ -894,10 +889,10 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             tm.end(e);
             HIP_TRY(hipGetLastError());
 
-            // out_proj + residual + LayerNorm(s) in one row-owning kernel (bf16 mode, full grids): outproj_ln_bf16.h
-            const bool ln_fused = bf && !h->no_ln_fusion && rows % OL_BM == 0 && (h->ol_v1 ? (rows / OL_BM) * 2 >= 256 : (rows / OC_BM) * 2 >= h->rowblock_min_wgs);
-            if (ln_fused && !h->ol_v1) {
-                // second design: 64-row blocks on the refinement chain's structure (outproj_ln_chain_bf16.h); same bits
+            // out_proj + residual + LayerNorm(s) in one row-owning kernel (bf16 mode, full grids): 64-row blocks on the refinement chain's
+            // structure (outproj_ln_chain_bf16.h); same bits as the GEMM + LayerNorm kernels
+            const bool ln_fused = bf && !h->no_ln_fusion && rows % OC_BM == 0 && (rows / OC_BM) * 2 >= h->rowblock_min_wgs;
+            if (ln_fused) {
                 OutLnChainArgs oa;
                 memset(&oa, 0, sizeof(oa));
                 for (int m = 0; m < 2; ++m) {
@@ -915,27 +910,6 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 #endif
                 e = tm.begin(ST_OUT);
                 hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
-                tm.end(e);
-                tm.gemm_launches += 1;
-                HIP_TRY(hipGetLastError());
-                cur[0] = xbuf[0];
-                cur[1] = xbuf[1];
-                continue;
-            }
-            if (ln_fused) {
-                OutLnArgs oa;
-                memset(&oa, 0, sizeof(oa));
-                for (int m = 0; m < 2; ++m) {
-                    OutLnProblem& q = oa.p[m];
-                    q.A = attb[m]; q.W = h->out_wb[m][l]; q.bias = h->out_b[m][l]; q.R = cur[m];
-                    q.g1 = h->norm_w[m][l]; q.b1 = h->norm_b[m][l];
-                    if (l == L - 1) { q.g2 = h->whiten_w[m]; q.b2 = h->whiten_b[m]; }
-                    q.y = (l < L - 1) ? xbuf[m] : nullptr;      // fp32 rows are only the next layer's residual
-                    q.yb = xb[m];
-                }
-                oa.M = rows; oa.eps = 1e-5f;
-                e = tm.begin(ST_OUT);
-                hipLaunchKernelGGL(iefvad_outproj_ln_bf16_kernel, dim3(rows / OL_BM, 2), dim3(512), OL_LDS_BYTES, stream, oa);
                 tm.end(e);
                 tm.gemm_launches += 1;
                 HIP_TRY(hipGetLastError());
@@ -1006,13 +980,12 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         }
         const bool tail_split = splitmb && (!compacted || split_eligible(rows, IEF_D, IEF_D, 1));   // bf16x6: a small compact set runs on the fp32 kernels
 
-        // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion, heads_fused_bf16.h.  The four
-        // head tensors are stored only if the caller asked for them.
-        const bool heads_fused = bf && !h->no_heads_fusion && rows % HF_BM == 0 && (rows / HF_BM) * HF_NBLK >= (h->heads_v1 ? 256 : h->rowblock_min_wgs);
-        // 4 + 5 in one kernel (bf16 mode, full grids): the K refinement steps and the scorer with the state on chip, refine_chain_bf16.h
+        // 2 + 3 in one kernel (bf16 mode, full grids): heads of both modalities + fusion on the row-block structure (heads_chain_bf16.h).
+        // The four head tensors are stored only if the caller asked for them.
+        const bool heads_rows = bf && !h->no_heads_fusion && h->heads_stream && rows % HC_BM == 0 && (rows / HC_BM) * HC_THIRDS >= h->rowblock_min_wgs;
+        const bool heads_fused = heads_rows;
+        // 4 + 5 in one kernel (bf16 mode): the K refinement steps and the scorer with the state on chip, refine_chain_bf16.h
         const bool chain = bf && K > 0 && !h->no_chain && h->chain_stream && rows % RC_BM == 0 && rows / RC_BM >= h->chain_min_blocks;
-        // second design: 64-row blocks on the row-block structure (heads_chain_bf16.h); same bits except the order of the row sums
-        const bool heads_rows = heads_fused && !h->heads_v1 && h->heads_stream && rows % HC_BM == 0 && (rows / HC_BM) * HC_THIRDS >= h->rowblock_min_wgs;
         if (heads_rows) {
             HeadsChainArgs ha;
             memset(&ha, 0, sizeof(ha));
@@ -1041,33 +1014,6 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 e = tm.begin(ST_FUSION);
                 hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
                                    wim_out, wem_out, rows, HC_NPART);
-                tm.end(e);
-                HIP_TRY(hipGetLastError());
-            }
-        } else if (heads_fused) {
-            HeadsFusedArgs ha;
-            memset(&ha, 0, sizeof(ha));
-            for (int m = 0; m < 2; ++m) { ha.A[m] = xtb[m]; ha.W[m] = h->head_wb[m]; ha.bias[m] = h->head_b[m]; }
-            ha.mu[0] = out->image_mu ? mu_i : nullptr;
-            ha.lv[0] = out->image_logvar ? lv_i : nullptr;
-            ha.mu[1] = out->event_mu ? mu_e : nullptr;
-            ha.lv[1] = out->event_logvar ? lv_e : nullptr;
-            ha.n[0] = out->w_i ? out->w_i + row0 * D : nullptr;
-            ha.n[1] = out->w_e ? out->w_e + row0 * D : nullptr;
-            ha.z = z;
-            ha.zb = chain ? nullptr : zb;      // the chain kernel reads the fp32 state only
-            const bool means = wim_out || wem_out;
-            ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 24 of its 768 floats per row
-            ha.M = rows; ha.factor = factor; ha.eps = c.epsilon;
-            hipEvent_t e = tm.begin(ST_HEAD);
-            hipLaunchKernelGGL(iefvad_heads_fused_bf16_kernel, dim3((rows / HF_BM) * HF_NBLK), dim3(512), HF_LDS_BYTES, stream, ha);
-            tm.end(e);
-            tm.gemm_launches += 1;
-            HIP_TRY(hipGetLastError());
-            if (means) {
-                e = tm.begin(ST_FUSION);
-                hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
-                                   wim_out, wem_out, rows, HF_NBLK);
                 tm.end(e);
                 HIP_TRY(hipGetLastError());
             }
@@ -1808,47 +1754,22 @@ static void stream_copy(char* d, const char* s, size_t n) {
     memcpy(d + body, s + body, n - body);
 }
 
+static void host_gather_run(char* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int threads);
+
 extern "C" int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
     if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather: null argument");
     if (count == 0) return 0;
-    std::vector<size_t> off((size_t)count + 1);
-    off[0] = 0;
-    for (int64_t i = 0; i < count; ++i) {
+    for (int64_t i = 0; i < count; ++i)
         if (nbytes[i] && !srcs[i]) return fail("iefvad_host_gather: srcs[%lld] is null", (long long)i);
-        off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
-    }
-    const size_t total = off[(size_t)count];
-    int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    if (total < ((size_t)4 << 20)) nt = 1;               // a few MB: one thread is done before a second one has started
-    auto run = [&](int64_t a, int64_t b) {
-        for (int64_t i = a; i < b; ++i)
-            if (nbytes[i]) stream_copy((char*)dst + off[(size_t)i], (const char*)srcs[i], nbytes[i]);
-        __builtin_ia32_sfence();                          // the non-temporal stores are globally visible before the caller starts a DMA
-    };
-    if (nt == 1) {
-        run(0, count);
-        return 0;
-    }
-    // contiguous runs of pieces, ~equal bytes each
-    std::vector<int64_t> cut((size_t)nt + 1, count);
-    cut[0] = 0;
-    int k = 1;
-    for (int64_t i = 0; i < count && k < nt; ++i)
-        if (off[(size_t)i + 1] >= total / nt * k) cut[(size_t)k++] = i + 1;
-    std::vector<std::thread> pool;
     try {
-        for (int t = 1; t < nt; ++t)
-            if (cut[(size_t)t + 1] > cut[(size_t)t]) pool.emplace_back(run, cut[(size_t)t], cut[(size_t)t + 1]);
-    } catch (...) {                                       // thread creation refused: finish the rest here
-        for (auto& th : pool) th.join();
-        run(cut[1], count);
-        run(0, cut[1]);
-        return 0;
+        host_gather_run((char*)dst, srcs, nbytes, count, threads);
+    } catch (const std::exception& e) {
+        return fail("iefvad_host_gather: %s", e.what());
     }
-    run(0, cut[1]);
-    for (auto& th : pool) th.join();
     return 0;
 }
+
+#include "hostpipe.h"
 
 extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                                 int32_t compute, void* stream) {

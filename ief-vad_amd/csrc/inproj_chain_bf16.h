@@ -12,7 +12,7 @@
 // The 256 x 256 ring kernel (gemm_bf16.h) re-reads a 96 KB A panel nine times through L2 for 256 rows and stops at every
 // k-tile barrier; here the weights move (3.5 MB per block, the measured 110-120 GB/s per CU) and the rows stay.
 // Same products in the same k order, the ring kernel's epilogue arithmetic ((acc + b) * s -> bf16): bit-identical q | k | v
-// (IEFVAD_NO_INPROJ_CHAIN=1 selects the ring kernel for the A/B).
+// (IEFVAD_ROWBLOCK_OFF=1 selects the ring kernel for the A/B).
 #pragma once
 #include "outproj_ln_chain_bf16.h"
 

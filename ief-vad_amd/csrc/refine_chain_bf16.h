@@ -19,7 +19,7 @@
 //   * the MFMA is issued with the operands swapped (A = weight fragment, B = activation fragment), so a lane holds four
 //     CONSECUTIVE output columns of one row: h / bf16(z) go back into the image as one 8-byte LDS store per tile, and the
 //     products and their k order are those of the projection kernels (gemm_bf16.h): z and the logits are bit-identical
-//     to the 2K-launch path (tests/test_gpu_bf16.py, IEFVAD_NO_CHAIN=1 is the A/B switch);
+//     to the 2K-launch path (tests/test_gpu_bf16.py, IEFVAD_ROWBLOCK_OFF=8 is the A/B switch);
 //   * the scorer runs on the resident state: the final z is parked in LDS (fp32, 32 rows at a time) and reduced by the
 //     scorer kernel's own code, 4 bytes per snippet leave the chip (plus z itself when the caller asked for `fused`).
 // HBM traffic of the tail per snippet: 3 KB in (z from the heads + fusion kernel), 4 B out, against 10 x 12 KB.

@@ -355,7 +355,7 @@ class _RowStager:
 
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
                  label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True, lanes: int = 1,
-                 ragged: Optional[bool] = None):
+                 ragged: Optional[bool] = None, host_list: bool = True, host_list_bytes: int = 1 << 30):
     """Per-video sigmoid scores and mean fusion weights, in loader order.
 
     batch_chunks == 0: one forward per video with B = that video's chunk count -- the reference's call
@@ -368,6 +368,10 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     the packed batches go through `MMFMIL.forward_videos` -- only the VALID rows of every video are staged and uploaded, the
     chunker, the conditional nan_to_num (test.py:90-95) and the `[0:len]` slicing run on the device, and no stage computes the
     padding (one pad row per chunk stands for all of them, csrc/ragged.h).  Same scores (bit for bit in the f32 and bf16 modes).
+
+    `host_list` (default; ragged mode with host-resident loader tensors): the walk over the list happens inside the library
+    (`iefvad_forward_videos_host`): Python hands over each video's tensor and length, the library packs, stages, sends and scores
+    pass by pass with its own worker thread and copy stream -- one call per `host_list_bytes` of features.  `lanes` is not used then.
 
     lanes > 1 (HIP devices, `iefvad_amd.MMFMIL`): consecutive forwards go round-robin to `lanes` HIP streams, each with a
     lane of the model (`MMFMIL.lanes`: same parameters, own library handle and workspace) and its own pinned staging.
@@ -484,6 +488,51 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
         total = off
         pend, pend_chunks = [], 0
 
+    # packed valid-row loop with the walk inside the library (`MMFMIL.forward_videos_host`, csrc/hostpipe.h): this thread only
+    # collects each video's host tensor and length; one library call per `host_list_bytes` of features stages, sends and scores
+    # them pass by pass.  Same batches, same kernels as the loop below (which remains for models without the entry, lanes > 1
+    # callers that ask for it with host_list=False, and device-resident loaders).
+    use_list = bool(ragged and host_list and hasattr(model, 'forward_videos_host'))
+    if use_list:
+        group: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
+        gbytes = 0
+
+        def flush_list():
+            nonlocal group, gbytes, total
+            if not group:
+                return
+            out = model.forward_videos_host([g[0] for g in group], [g[1] for g in group], [g[2] for g in group], nan_to_num=True,
+                                            batch_chunks=batch_chunks)
+            dev_prob.append(out['logits'])
+            dev_wi.append(out['w_i_mean'])
+            dev_we.append(out['w_e_mean'])
+            off = total
+            for _, _, n in group:
+                spans.append((off, n))
+                off += n
+            total = off
+            group, gbytes = [], 0
+
+        with torch.no_grad():
+            for item in test_loader:
+                img, ev, cls, n = _unpack_rows(item, maxlen, dataset, label_map)
+                classes.append(cls)
+                if img.is_cuda or ev.is_cuda:
+                    raise ValueError("host_list=True expects the loader's tensors in host memory")
+                if img.dtype != ev.dtype or img.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                    # the model widens both with `.to(torch.float)` (imf_vad.py:41-42); the NaN rule applies in the file's own dtype first
+                    img, ev = (torch.nan_to_num(t, nan=0.0) if _has_nan(t) else t for t in (img, ev))
+                    img, ev = img.float(), ev.float()
+                if group and group[0][0].dtype != img.dtype:
+                    flush_list()                                  # a library call takes one feature dtype
+                group.append((img, ev, n))
+                gbytes += 2 * n * img.shape[-1] * img.element_size()
+                if gbytes >= host_list_bytes:
+                    flush_list()
+            flush_list()
+        test_loader = ()
+        ragged = False
+
     with torch.no_grad():
         try:
             for item in test_loader:
@@ -513,14 +562,15 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             for s in streams:
                 torch.cuda.current_stream(device).wait_stream(s)
         if dev_prob:
-            prob = torch.sigmoid(torch.cat(dev_prob)).cpu().numpy()       # logits1[0:len_cur] -> sigmoid, test.py:119-121
-            wi = torch.cat(dev_wi).cpu().numpy()
-            we = torch.cat(dev_we).cpu().numpy()
+            # ONE device-to-host copy for the three vectors (sigmoid on the device: logits1[0:len_cur] -> sigmoid, test.py:119-121)
+            allv = torch.stack([torch.sigmoid(torch.cat(dev_prob)), torch.cat(dev_wi), torch.cat(dev_we)]).cpu().numpy()
+            prob, wi, we = allv[0], allv[1], allv[2]
         else:
             prob = wi = we = np.zeros(0, np.float32)
-    scores = [prob[o:o + n].copy() for o, n in spans]
-    wi_means = [wi[o:o + n].copy() for o, n in spans]
-    we_means = [we[o:o + n].copy() for o, n in spans]
+    # per-video views of the three host vectors (contiguous spans in loader order; padded routes leave gaps between them)
+    scores = [prob[o:o + n] for o, n in spans]
+    wi_means = [wi[o:o + n] for o, n in spans]
+    we_means = [we[o:o + n] for o, n in spans]
     return scores, classes, wi_means, we_means
 
 

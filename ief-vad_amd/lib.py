@@ -27,7 +27,8 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
-           "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward"]
+           "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward",
+           "iefvad_forward_videos_host"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -122,6 +123,9 @@ def load_library() -> C.CDLL:
     lib.iefvad_forward_videos.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
                                           C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.iefvad_forward_videos.restype = C.c_int
+    lib.iefvad_forward_videos_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
+                                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.iefvad_forward_videos_host.restype = C.c_int
     lib.iefvad_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.iefvad_loss_workspace_bytes.restype = C.c_size_t
     lib.iefvad_loss_forward.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,

@@ -428,6 +428,51 @@ class MMFMIL(nn.Module):
             return {k: res[k] for k in OUTPUT_KEYS}   # the reference's key order
         return res
 
+    def forward_videos_host(self, imgs, evs, lengths, nan_to_num: bool = True, batch_chunks: int = 128, host_threads: int = 0
+                            ) -> Dict[str, torch.Tensor]:
+        """A whole list of videos in ONE library call (`iefvad_forward_videos_host`): `imgs[v]`, `evs[v]` are contiguous HOST tensors
+        of one dtype whose first `lengths[v]` rows ([..., D]) are video v's features -- e.g. the padded tensors a DataLoader
+        delivers (data/dataset.py:34-52).  The library packs whole videos into passes of >= `batch_chunks` chunks, stages and sends
+        pass k + 1 while pass k computes, and returns DEVICE vectors `logits`, `w_i_mean`, `w_e_mean` of [sum(lengths)] in list
+        order (stream-ordered on the current stream).  Same results as `forward_videos` on the same batches."""
+        if self.training:
+            raise RuntimeError("iefvad_amd.MMFMIL.forward_videos_host is an evaluation entry point; call model.eval() first")
+        self._noise_code()
+        lens = [int(n) for n in lengths]
+        if not lens or min(lens) < 1 or len(imgs) != len(lens) or len(evs) != len(lens):
+            raise ValueError("imgs, evs and lengths must list the same videos, every video at least one snippet")
+        dt = imgs[0].dtype
+        D = self.temporal.embed_dim
+        if dt not in _IN_DTYPES:
+            raise ValueError(f"feature dtype {dt} is not supported by the list entry (fp32, fp16 or bf16)")
+        n = len(lens)
+        # validation as C-speed sweeps (a per-video Python loop costs more than the library call on lists of short videos)
+        for parts in (imgs, evs):
+            if any(t.dtype != dt for t in parts) or any(t.is_cuda for t in parts) or not all(t.is_contiguous() for t in parts) \
+                    or any(t.shape[-1] != D for t in parts) or any(t.numel() < ln * D for t, ln in zip(parts, lens)):
+                raise ValueError(f"expected contiguous host tensors of dtype {dt} with at least lengths[v] rows of {D} each")
+        pi = (C.c_void_p * n)(*[t.data_ptr() for t in imgs])
+        pe = (C.c_void_p * n)(*[t.data_ptr() for t in evs])
+        device = next(self.temporal.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("iefvad_amd.MMFMIL runs on a HIP device only; there is no CPU fallback (call model.to('cuda'))")
+        total = sum(lens)
+        lib = _lib.load_library()
+        larr = (C.c_int32 * n)(*lens)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            self._ensure_handle(device)
+            self._ensure_weights(device, stream)
+            f32 = dict(dtype=torch.float32, device=device)
+            res = {"logits": torch.empty(total, **f32), "w_i_mean": torch.empty(total, **f32), "w_e_mean": torch.empty(total, **f32)}
+            rc = lib.iefvad_forward_videos_host(self._handle, pi, pe, _IN_DTYPES[dt], larr, n, 1 if nan_to_num else 0, int(batch_chunks),
+                                                int(host_threads), C.c_void_p(res["logits"].data_ptr()),
+                                                C.c_void_p(res["w_i_mean"].data_ptr()), C.c_void_p(res["w_e_mean"].data_ptr()),
+                                                C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("iefvad_forward_videos_host: " + _lib.last_error())
+        return res
+
     # ------------------------------------------------------------------ train mode
     def _forward_train(self, img_visual, ev_visual) -> Dict[str, torch.Tensor]:
         """`model.train()` forward (/root/reference/train/ucf_train.py:43,60-66): the same dict, differentiable with respect to

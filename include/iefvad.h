@@ -183,6 +183,21 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
                           const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, void* workspace,
                           size_t workspace_bytes, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
 
+/* The whole evaluation LIST in one call: host rows in, per-snippet results on the device.  Replaces the Python loop around
+ * iefvad_forward_videos (one iteration per video in the reference, /root/reference/test.py:76-121; one per packed batch in this
+ * package until round 3): the library cuts the list into passes of >= batch_chunks chunks (whole videos; 0 = 128), a worker thread
+ * gathers the rows of pass k + 1 into pinned staging (host_threads copy threads, 0 = 4) while this thread sends pass k on an
+ * internal copy stream and enqueues its forward on `stream`; results land in list order.
+ *   img_rows, ev_rows   HOST arrays of nvideos HOST pointers: video v's [lengths[v], D] feature rows of `in_dtype`, contiguous
+ *                       (e.g. the first lengths[v] rows of the zero-padded tensor a DataLoader delivers)
+ *   logits, w_i_mean, w_e_mean   DEVICE, [sum(lengths)] fp32 each (the means nullable), valid once `stream` has run
+ * Returns when every pass has been enqueued and every host row has been read (the caller's host tensors are free again);
+ * staging slots, device input slots and the workspace belong to the handle.  Same results as iefvad_forward_videos on the
+ * same batches. */
+int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, const void* const* ev_rows, int32_t in_dtype,
+                               const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
+                               int32_t host_threads, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
+
 /* ---- training-side loss head: forward, and its gradients w.r.t. the model's outputs -----------------
  * The three terms the reference's trainers add up (/root/reference/train/ucf_train.py:68-101, train/xd_train.py:60-75), as
  * device reductions over tensors iefvad_forward already produces:

@@ -204,3 +204,62 @@ def test_forward_videos_matches_the_oracle_and_rejects_bad_arguments():
         model.forward_videos(img, img, [10, 0])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.forward_videos(img.cpu(), img.cpu(), [10])
+
+
+@pytest.mark.parametrize("compute,batch_chunks", [("f32", 4), ("f32", 128), ("bf16", 8)])
+def test_host_list_entry_equals_forward_videos(compute, batch_chunks):
+    """`iefvad_forward_videos_host` (csrc/hostpipe.h): the library walks the list -- packs whole videos into passes, stages pass k + 1
+    on a worker thread while pass k is sent and computed -- from the HOST tensors a DataLoader delivers (zero-padded chunk tensors
+    whose first `len` rows count).  Bit-identical to one `forward_videos` call over the same rows whatever the pass sizes (the
+    library ramps them up and tapers them): the f32 mode is bit-reproducible across batch sizes, and the bf16 mode's ring and
+    row-block kernels are bit-identical to each other (only the fusion weights' row sums are added in another order).  Called
+    twice: the second call reuses the handle's staging slots and copy threads."""
+    lengths = EDGE_LENGTHS + [90, 400, 33]
+    vids = videos(lengths, seed=23)
+    model, _ = make_model(compute, outputs="scores")
+    padded_i = [torch.from_numpy(harness.process_split(v[0], 256)[0]) for v in vids]
+    padded_e = [torch.from_numpy(harness.process_split(v[1], 256)[0]) for v in vids]
+    for _ in range(2):
+        got = model.forward_videos_host(padded_i, padded_e, lengths, batch_chunks=batch_chunks)
+    want = ragged(model, vids)
+    for k in want:
+        assert got[k].shape == (sum(lengths),)
+        if compute == "bf16" and k != "logits":
+            assert float((got[k] - want[k]).abs().max()) <= 1e-6, k          # row sums of the fusion weights: order depends on the kernel
+        else:
+            assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+    with pytest.raises(ValueError, match="contiguous host tensors"):
+        model.forward_videos_host([padded_i[0].cuda()], [padded_e[0]], [lengths[0]])
+    with pytest.raises(ValueError, match="same videos"):
+        model.forward_videos_host(padded_i, padded_e[:-1], lengths)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_score_loader_host_list_equals_the_python_loop(dtype):
+    """harness.score_loader: the list walk inside the library (host_list=True, the default) against the Python loop around
+    forward_videos (host_list=False) -- same batches, same scores bit for bit, incl. the NaN rule, an fp16 video inside an fp32 list
+    (a dtype change closes a library call) and several calls per list (host_list_bytes)."""
+    lengths = [100, 300, 50, 80, 600, 256, 17, 900]
+    vids = videos(lengths, seed=29, dtype=dtype)
+    vids[1][0][7, 5] = np.nan
+    vids[1][0][290, 100] = np.inf
+    vids[3][0][10, 10] = np.inf
+    vids[4][1][400, 767] = np.nan
+    if dtype == np.float32:
+        vids[6] = (vids[6][0].astype(np.float16), vids[6][1].astype(np.float16))
+    model, _ = make_model("f32", outputs="scores")
+
+    def items():
+        for img, ev in vids:
+            ci, n = harness.process_split(img, 256)
+            ce, _ = harness.process_split(ev, 256)
+            yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
+
+    loop, _, wi_l, we_l = harness.score_loader(model, items(), 256, "cuda:0", "ucfcrime", batch_chunks=4, host_list=False)
+    for cap in (1 << 30, 1 << 20):
+        lst, _, wi_h, we_h = harness.score_loader(model, items(), 256, "cuda:0", "ucfcrime", batch_chunks=4, host_list_bytes=cap)
+        for i, (a, b) in enumerate(zip(loop, lst)):
+            assert a.shape == (lengths[i],) and np.array_equal(np.isnan(a), np.isnan(b)), i
+            assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0)), i
+        for a, b in zip(wi_l + we_l, wi_h + we_h):
+            assert np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
