@@ -33,16 +33,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Sum / maximum over the 64 lanes, result in every lane (wave-uniform).  DPP cross-lane operands instead of six ds_bpermute round
+// trips through the LDS crossbar (~100 cycles each, and a row-wise epilogue runs four such chains per row: outproj_ln_*chain,
+// LayerNorm backward ...): quad_perm (xor 1, xor 2), row_half_mirror, row_mirror -- after each step the lanes of the group hold
+// the same value, so which lane pairs with which does not matter --, then row_bcast:15 / row_bcast:31 fold the four 16-lane rows
+// and lane 63 holds the total.  The summation TREE is the xor butterfly's taken in ascending order (1, 2, 4, 8, 16, 32): every
+// kernel reduces through these two functions, so all of them stay bit-identical to each other.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_take<0xB1, 0xF>(v, v);          // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v, v);          // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v, v);         // row_half_mirror: the other quad of the 8-lane group
+    v += dpp_take<0x140, 0xF>(v, v);         // row_mirror: the other half of the 16-lane row
+    v += dpp_take<0x142, 0xA>(0.f, v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(0.f, v);       // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_take<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_take<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Running maximum of |x| over a tensor (fp16x3 mode: the power-of-two operand scale of the next projection), kept in

@@ -26,6 +26,7 @@
 #include "rowops.h"
 #include "refine_chain_bf16.h"
 #include "outproj_ln_chain_bf16.h"
+#include "outproj_ln_pchain_bf16.h"
 #include "inproj_chain_bf16.h"
 #include "heads_chain_bf16.h"
 #include "ragged.h"
@@ -117,6 +118,7 @@ struct iefvad_handle {
     struct EventPool* events;   // hipEvents of iefvad_forward_timed, reused across calls
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
     struct MetaRing* meta;      // pinned / device metadata buffers of iefvad_forward_videos
+    int num_cus;                // compute units of the device: grid size of the persistent row-block kernels
     struct HostPipe* hostpipe;  // staging slots, copy stream and workspace of iefvad_forward_videos_host (hostpipe.h)
     struct TrainState* train;   // records of the train-mode forwards whose backward is outstanding (train.h)
 };
@@ -191,6 +193,14 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OC_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OP_LDS_BYTES);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, h->device);
+        h->num_cus = e == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB2_LDS_BYTES);
@@ -908,8 +918,15 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 #ifdef OC_DIAG
                 { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_OC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); oa.diag = dg; }
 #endif
+                // from two blocks per workgroup on: the persistent kernel, one workgroup per CU, the next block's image fetched during the
+                // LayerNorm epilogue (outproj_ln_pchain_bf16.h; same bits); IEFVAD_PERSIST=0 keeps the one-block-per-workgroup kernels (A/B)
+                static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
+                const int gx = h->num_cus / 2;
                 e = tm.begin(ST_OUT);
-                hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
+                if (persist && rows / OC_BM >= 2 * gx)
+                    hipLaunchKernelGGL(iefvad_outproj_ln_pchain_bf16_kernel, dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
+                else
+                    hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
                 tm.end(e);
                 tm.gemm_launches += 1;
                 HIP_TRY(hipGetLastError());

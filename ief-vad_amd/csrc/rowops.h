@@ -69,9 +69,7 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[R][3], const float* g, const 
         for (int j = 0; j < 3; ++j) s[r] += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    for (int r = 0; r < R; ++r) s[r] = wave_sum(s[r]);      // R independent DPP chains: the scheduler interleaves them
     float ss[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -87,9 +85,7 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[R][3], const float* g, const 
             }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < R; ++r) ss[r] += __shfl_xor(ss[r], o, 64);
+    for (int r = 0; r < R; ++r) ss[r] = wave_sum(ss[r]);
     f32x4 gv[3], bv[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
