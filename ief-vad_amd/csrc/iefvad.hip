@@ -29,6 +29,7 @@
 #include "outproj_ln_pchain_bf16.h"
 #include "inproj_chain_bf16.h"
 #include "heads_chain_bf16.h"
+#include "heads_pchain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
 #include "backward.h"
@@ -196,6 +197,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OP_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_heads_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HP_LDS_BYTES);
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, h->device);
@@ -1022,8 +1026,15 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 #ifdef HC_DIAG
             { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_HC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ha.diag = dg; }
 #endif
+            // from two blocks per workgroup on: the persistent kernel (heads_pchain_bf16.h: one workgroup per CU and column third, both
+            // images by LDS-DMA under the previous block's epilogue / the first part of phase 2; same bits); IEFVAD_PERSIST=0: A/B
+            static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
+            const int gx = h->num_cus / HC_THIRDS;
             hipEvent_t e = tm.begin(ST_HEAD);
-            hipLaunchKernelGGL(iefvad_heads_chain_bf16_kernel, dim3(rows / HC_BM, HC_THIRDS), dim3(512), HC_LDS_BYTES, stream, ha);
+            if (persist && rows / HC_BM >= 2 * gx)
+                hipLaunchKernelGGL(iefvad_heads_pchain_bf16_kernel, dim3(gx, HC_THIRDS), dim3(512), HP_LDS_BYTES, stream, ha);
+            else
+                hipLaunchKernelGGL(iefvad_heads_chain_bf16_kernel, dim3(rows / HC_BM, HC_THIRDS), dim3(512), HC_LDS_BYTES, stream, ha);
             tm.end(e);
             tm.gemm_launches += 1;
             HIP_TRY(hipGetLastError());

@@ -31,58 +31,51 @@ struct LnArgs {
     float* amax[2];          // fp16x3 mode: running max |y| of the output tensor (nullable)
 };
 
+// The per-row arithmetic is written on 4-vectors (hipcc maps them to v_pk_add / v_pk_mul / v_pk_fma_f32: two fp32 lanes per
+// instruction): a LayerNorm epilogue of a row-block kernel is VALU-issue bound (~1,300 scalar instructions per wave and 64-row
+// block at two waves per SIMD), not memory bound.  ln_row and ln_rows perform the SAME operations per row in the same order, so the
+// stand-alone kernel and every fused epilogue agree bit for bit.
+__device__ __forceinline__ float ln_hsum(f32x4 t) { return (t[0] + t[1]) + (t[2] + t[3]); }
+
 __device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const float* b, int lane, float eps) {
-    float s = 0.f;
+    const float mean = wave_sum(ln_hsum((v[0] + v[1]) + v[2])) * (1.0f / IEF_D);
+    const f32x4 m4 = {mean, mean, mean, mean};
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    const float mean = wave_sum(s) * (1.0f / IEF_D);
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[j][e] - mean;
-            v[j][e] = d;
-            ss += d * d;
-        }
-    const float var = wave_sum(ss) * (1.0f / IEF_D);
+    for (int j = 0; j < 3; ++j) v[j] = v[j] - m4;
+    f32x4 sq = v[0] * v[0];
+    sq = v[1] * v[1] + sq;
+    sq = v[2] * v[2] + sq;
+    const float var = wave_sum(ln_hsum(sq)) * (1.0f / IEF_D);
     const float rstd = 1.0f / sqrtf(var + eps);
+    const f32x4 r4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const f32x4 gv = *(const f32x4*)(g + 4 * lane + 256 * j);
         const f32x4 bv = *(const f32x4*)(b + 4 * lane + 256 * j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * rstd * gv[e] + bv[e];
+        v[j] = (v[j] * r4) * gv + bv;
     }
 }
 
 // ln_row on R rows of one wave at a time: the same operations per row in the same order, with the R independent reduction
-// chains (two 6-step shuffle trees per row, each step a dependent LDS-crossbar round trip) interleaved.  For callers with few
-// resident waves (outproj_ln_chain_bf16.h: two per SIMD), where one row after the other costs ~1,700 cycles per LayerNorm.
+// chains interleaved.  For callers with few resident waves (outproj_ln_*chain_bf16.h: two per SIMD).
 template <int R>
 __device__ __forceinline__ void ln_rows(f32x4 (&v)[R][3], const float* g, const float* b, int lane, float eps) {
     float s[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        s[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) s[r] += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
-    }
+    for (int r = 0; r < R; ++r) s[r] = ln_hsum((v[r][0] + v[r][1]) + v[r][2]);
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = wave_sum(s[r]);      // R independent DPP chains: the scheduler interleaves them
     float ss[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float mean = s[r] * (1.0f / IEF_D);
-        ss[r] = 0.f;
+        const f32x4 m4 = {mean, mean, mean, mean};
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[r][j][e] - mean;
-                v[r][j][e] = d;
-                ss[r] += d * d;
-            }
+        for (int j = 0; j < 3; ++j) v[r][j] = v[r][j] - m4;
+        f32x4 sq = v[r][0] * v[r][0];
+        sq = v[r][1] * v[r][1] + sq;
+        sq = v[r][2] * v[r][2] + sq;
+        ss[r] = ln_hsum(sq);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) ss[r] = wave_sum(ss[r]);
@@ -96,10 +89,9 @@ __device__ __forceinline__ void ln_rows(f32x4 (&v)[R][3], const float* g, const 
     for (int r = 0; r < R; ++r) {
         const float var = ss[r] * (1.0f / IEF_D);
         const float rstd = 1.0f / sqrtf(var + eps);
+        const f32x4 r4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[r][j][e] = v[r][j][e] * rstd * gv[j][e] + bv[j][e];
+        for (int j = 0; j < 3; ++j) v[r][j] = (v[r][j] * r4) * gv[j] + bv[j];
     }
 }
 
