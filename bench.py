@@ -60,7 +60,8 @@ PROFILE_ROUNDS = ("r04", "r03")                                 # profiles/<roun
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
                "bf16": "iefvad_inproj_chain_f32in_kernel / iefvad_inproj_chain_bf16_kernel (in_proj; the first layer rounds the fp32 "
                        "rows to bf16 itself) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + scorer, one launch) + "
-                       "iefvad_heads_chain_bf16_kernel (heads + fusion) + iefvad_outproj_ln_chain_bf16_kernel (out_proj + LayerNorm)",
+                       "iefvad_heads_pchain_bf16_kernel (heads + fusion, persistent) + iefvad_outproj_ln_pchain_bf16_kernel (out_proj + LayerNorm, "
+                       "persistent)",
                "bf16x6": "iefvad_gemm_split_n128_kernel", "fp16x3": "iefvad_gemm_split_f16_n128_kernel"}
 PRODUCTS_PER_MAC = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "fp16x3": 3.0}
 DTYPE = {"f32": "f32", "bf16": "bf16",
@@ -174,8 +175,8 @@ def roofline_block(compute, stage, steps, rows_per_step):
         pure_ms = (stage["qkv_gemm_ms"] + stage["refine_gemm_ms"]) / steps
         r["achieved_pure_projection_launches"] = pure_flops / (pure_ms * 1e-3) / 1e12
         r["note"] = ("the 25 projections of a pass run as 6 launches of row-block kernels (a workgroup keeps 64 rows in LDS and every "
-                     "wave streams its own weight columns): 2 x in_proj, 2 x iefvad_outproj_ln_chain_bf16_kernel (out_proj + "
-                     "residual + LayerNorm), iefvad_heads_chain_bf16_kernel (both modalities' heads AND the precision-weighted "
+                     "wave streams its own weight columns): 2 x in_proj, 2 x iefvad_outproj_ln_pchain_bf16_kernel (out_proj + "
+                     "residual + LayerNorm), iefvad_heads_pchain_bf16_kernel (both modalities' heads AND the precision-weighted "
                      "fusion) and ONE iefvad_refine_chain_bf16_kernel (the 2K refinement projections and the scorer, state on "
                      "chip); the fused launches are counted whole as GEMM time and the stand-alone LayerNorm / fusion / scorer "
                      "kernels do not run.  achieved_pure_projection_launches = the same quantity over the in_proj and "

@@ -118,6 +118,10 @@ struct HostPipe {
 static void release_hostpipe(iefvad_handle* h) {
     HostPipe* p = h->hostpipe;
     if (!p) return;
+    // nothing of an earlier call may still be copying out of the pinned slots or computing in the workspaces
+    if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
+    for (int l = 0; l < HostPipe::kLanes; ++l)
+        if (p->lane[l]) (void)hipStreamSynchronize(p->lane[l]);
     for (int s = 0; s < HostPipe::kSlots; ++s) {
         for (int m = 0; m < 2; ++m) {
             if (p->pinned[s][m]) (void)hipHostFree(p->pinned[s][m]);

@@ -3,7 +3,7 @@
 # Writes everything under gpurun_out/<round>/; the summaries worth keeping are copied to profiles/<round>_* afterwards
 # (tools/keep_profiles.sh).  `head` = the commit the box's snapshot was taken from (there is no .git on the box).
 set -u
-RND="${1:-r03}"
+RND="${1:-r04}"
 HEAD="${2:-unknown}"
 export IEFVAD_HEAD="$HEAD"
 R="$PWD"
@@ -34,7 +34,7 @@ for mode in bf16 bf16x6; do
   python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_$mode" "$O/pmc_fetch_$mode" "$O/pmc_write_$mode" > "$O/pmc_summary_$mode.txt" 2>&1
 done
 SRC="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on python3 bench.py --steps 1 --warmup 1 --chunks 1024"
-K="iefvad_inproj_chain_f32in_kernel|iefvad_inproj_chain_bf16_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_chain_bf16_kernel|iefvad_outproj_ln_chain_bf16_kernel"
+K="iefvad_inproj_chain_f32in_kernel|iefvad_inproj_chain_bf16_kernel|iefvad_refine_chain_bf16_kernel|iefvad_heads_pchain_bf16_kernel|iefvad_outproj_ln_pchain_bf16_kernel"
 # algorithmic bytes of the six projection launches of a 262,144-row pass (bf16 mode, outputs=scores), KB per row, both modalities:
 # in_proj x2: read 6 (fp32 rows, layer 0) / 3 (bf16 rows, layer 1), write 9 (bf16 q|k|v); out_proj+LN x2: read 3 + 6 (fp32 residual),
 # write 6 fp32 + 3 bf16 (layer 0) / 3 bf16 (layer 1); heads+fusion: read 3, write 3 (fp32 z) + 0.2; refinement chain: read 3 (z), write 0.004
@@ -67,6 +67,21 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_c
 python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_cfg5" "$O/pmc_fetch_cfg5" "$O/pmc_write_cfg5" > "$O/pmc_summary_config5.txt" 2>&1
 echo "[7] packed evaluation loop: where the wall clock goes"
 python3 "$R/tools/ragged_profile.py" > "$O/ragged_profile.log" 2>&1
+echo "[8] training step (ucf_train.py's configuration, B = 128): kernel stats"
+python3 "$R/tools/train_step_probe.py" > "$O/train_step.json" 2> "$O/train_step.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -o t -- python3 "$R/tools/train_step_probe.py" --steps 3 --warmup 1 \
+    > "$O/train_step_under_rocprof.json" 2> "$O/trace_train.log"
+python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_train" -name '*kernel_stats.csv' | head -1)" "$O/train_step_kernel_stats.csv" > /dev/null
+echo "[9] the evaluation list walked inside the library: phases of configs 3 and 5"
+IEFVAD_HOSTPIPE_TRACE=1 python3 "$R/tools/host_list_probe.py" > "$O/host_list_probe.log" 2> "$O/host_list_trace.log"
+grep hostpipe "$O/host_list_trace.log" | tail -16 >> "$O/host_list_probe.log"
+echo "[10] persistent out_proj + LayerNorm kernel: phase stamps (diag build)"
+if [ -f "$R/build/libiefvad_ocdiag.so" ]; then IEFVAD_LIB="$R/build/libiefvad_ocdiag.so" python3 "$R/tools/outproj_pdiag.py" > "$O/outproj_pchain_phase_stamps.log" 2>&1; fi
+for pz in 1 0; do
+  IEFVAD_PERSIST=$pz python3 "$B" --compute bf16 --steps 3 --warmup 1 $QUIET 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('IEFVAD_PERSIST=$pz', round(d['value']), 'snippets/s', round(d['ms_per_step'],2), 'ms/step', {k:round(v,2) for k,v in d['stage_ms_per_step'].items()})" >> "$O/persist_ab.log"
+done
 # keep the merge-back small: the raw traces are large
 find "$O" -name '*kernel_trace.csv' -size +8M -delete
 find "$O" -name '*.db' -delete

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of a collect_profiles.sh run (gpurun_out/<round>/) into profiles/<round>_* (tracked).
 set -eu
-RND="${1:-r03}"
+RND="${1:-r04}"
 O=gpurun_out/$RND
 cp $O/bench_default.json profiles/${RND}_bench_default.json.log
 for m in bf16x6 bf16 f32; do
@@ -21,4 +21,9 @@ cp $O/gemm_bf16_hbm_traffic.json profiles/${RND}_gemm_bf16_hbm_traffic.json
  echo "== GS_ZERO=1: tools/gemm_tune_split_clk"; cat $O/gemm_split_clk_zero1.log) > profiles/${RND}_gemm_split_zero_vs_random_operands.log
 cp $O/latency.log profiles/${RND}_small_batch_latency.log
 cp $O/ragged_profile.log profiles/${RND}_packed_eval_loop_profile.log
+cp $O/train_step.json profiles/${RND}_train_step.json.log
+cp $O/train_step_kernel_stats.csv profiles/${RND}_train_step_kernel_stats.csv
+cp $O/host_list_probe.log profiles/${RND}_host_list_probe.log
+[ -f $O/outproj_pchain_phase_stamps.log ] && cp $O/outproj_pchain_phase_stamps.log profiles/${RND}_outproj_pchain_phase_stamps.log
+cp $O/persist_ab.log profiles/${RND}_persistent_rowblock_ab.log
 echo kept
