@@ -370,12 +370,12 @@ def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=
     harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)          # warm-up: every lane
     torch.cuda.synchronize()
     dts = []
-    for _ in range(3):
+    for _ in range(7):                                 # a pass is 4 - 25 ms: seven of them, the median (single passes scatter by 2x on a shared host)
         t0 = time.perf_counter()
         scores, cls, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes)
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
-    dt = sorted(dts)[1]                                # median of three passes
+    dt = sorted(dts)[len(dts) // 2]
     chunks = sum((int(n) // T + (1 if int(n) % T else 0)) if int(n) >= T else 1 for p in parts for n in p[1])
     out = {"workload": f"{tag}: {' + '.join(p[0] for p in parts)} test list(s), {nvid} videos, {total} snippets ({chunks} chunks = "
                        f"{chunks * T} chunk rows), K={K}, projections={compute}; valid rows of consecutive videos packed into "
