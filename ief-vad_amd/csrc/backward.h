@@ -165,6 +165,23 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
         }
 }
 
+// dst[c][r] = src[r][c] (32 x 32 tiles through LDS): W^T for the transposed split planes of the bf16x6 backward (train.h)
+__global__ __launch_bounds__(256) void iefvad_transpose_f32_kernel(const float* src, float* dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // attention probabilities, train mode
 // ------------------------------------------------------------------------------------------------------------------------

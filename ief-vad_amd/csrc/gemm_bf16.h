@@ -274,7 +274,7 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
     const float alpha = args.alpha;
     const int rq = lane >> 5, cq = lane & 31;
     const int ncol = n0 + wcol0 + 4 * cq;
-    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE);
+    const bool has_resid = (epi == EPI_BIAS_RESID || epi == EPI_REFINE || epi == EPI_GATE);
     float* E = smem + wave * (32 * GB2_EPI_LD);       // 16.9 KB per wave
     const f32x4 bv = *(const f32x4*)(P.bias + ncol);
     float* C32 = P.C;
@@ -364,6 +364,10 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
                 for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
             } else if (epi == EPI_BIAS_RESID) v = v + res[u];
             else if (epi == EPI_REFINE) v = res[u] - alpha * v;
+            else if (epi == EPI_GATE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = res[u][e] > 0.f ? alpha * v[e] : 0.f;
+            }
             const size_t o = (size_t)(mrow + 2 * u) * ldc + nn;
             if (C32) GB2_STORE((f32x4*)(C32 + o), v);
             if (C16) {

@@ -28,6 +28,7 @@ enum GemmEpilogue {
     EPI_BIAS_RESID = 3,  // C = acc + bias + R                                out_proj + residual (x + attn_out)
     EPI_REFINE = 4,      // C = R - alpha * (acc + bias)                      z - lambda * block(z)
     EPI_HEADS = 5,       // n < 768: C = acc + bias ; n >= 768: C2 = acc + bias   (mu | logvar heads share A)
+    EPI_GATE = 6,        // C = R > 0 ? alpha * (acc + bias) : 0   (split kernel only: ReLU backward on the saved activation, train.h)
 };
 
 struct GemmProblem {

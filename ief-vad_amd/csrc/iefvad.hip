@@ -120,6 +120,11 @@ struct iefvad_handle {
     struct GraphCache* graphs;  // hipGraphs of small-batch forwards (cfg.graph_chunks)
     struct MetaRing* meta;      // pinned / device metadata buffers of iefvad_forward_videos
     int num_cus;                // compute units of the device: grid size of the persistent row-block kernels
+    // training in the bf16x6 arithmetic: three-plane splits of the TRANSPOSED projection matrices ([3][768][n_out]: dX = dY W as an NT
+    // product on the split kernel), rebuilt by the first train-mode forward after every iefvad_set_weights (train.h)
+    bf16_t* arena_st; float* tscratch; float* zero_bias; bool tplanes_valid;
+    bf16_t* in_wst[2][IEFVAD_MAX_LAYERS]; bf16_t* out_wst[2][IEFVAD_MAX_LAYERS]; bf16_t* head_wst[2];
+    bf16_t* ref_w1st[IEFVAD_MAX_STEPS]; bf16_t* ref_w2st[IEFVAD_MAX_STEPS];
     struct HostPipe* hostpipe;  // staging slots, copy stream and workspace of iefvad_forward_videos_host (hostpipe.h)
     struct TrainState* train;   // records of the train-mode forwards whose backward is outstanding (train.h)
 };
@@ -259,6 +264,9 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
             if (h->iproj_stream[m][l]) (void)hipFree(h->iproj_stream[m][l]);
         }
     if (h->arena_s) (void)hipFree(h->arena_s);
+    if (h->arena_st) (void)hipFree(h->arena_st);
+    if (h->tscratch) (void)hipFree(h->tscratch);
+    if (h->zero_bias) (void)hipFree(h->zero_bias);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
     release_events(h);
@@ -457,6 +465,7 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
         }
     }
     h->weights_set = true;
+    h->tplanes_valid = false;
     return 0;
 }
 

@@ -117,14 +117,62 @@ static int launch_bgemm(const BgemmArgs& a, bool akc, bool bkc, int nz, hipStrea
     return 0;
 }
 
+// bf16x6 handles: the three-plane splits of every TRANSPOSED projection matrix, so that dX = dY W runs as the NT product
+// dX[rows, 768] = dY[rows, n_out] (W^T)[768, n_out]^T on iefvad_gemm_split_n128_kernel (fp32-accurate, 1.7x the fp32 MFMA rate)
+static int ensure_train_planes(iefvad_handle* h, hipStream_t stream) {
+    if (h->cfg.compute != IEFVAD_COMPUTE_BF16X6 || h->tplanes_valid) return 0;
+    const int L = h->cfg.num_layers, K = h->cfg.num_steps;
+    const size_t D = IEF_D, DD = D * D;
+    const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
+    if (!h->arena_st) HIP_TRY(hipMalloc((void**)&h->arena_st, 3 * nb * sizeof(bf16_t)));
+    if (!h->tscratch) HIP_TRY(hipMalloc((void**)&h->tscratch, 3 * DD * sizeof(float)));
+    if (!h->zero_bias) {
+        HIP_TRY(hipMalloc((void**)&h->zero_bias, 3 * D * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(h->zero_bias, 0, 3 * D * sizeof(float), stream));
+    }
+    bf16_t* q = h->arena_st;
+    auto tsplit = [&](bf16_t** dst, const float* W, int n_out) -> int {      // W [n_out, 768] -> planes of W^T [768, n_out]
+        *dst = q;
+        q += 3 * (size_t)n_out * D;
+        hipLaunchKernelGGL(iefvad_transpose_f32_kernel, dim3(IEF_D / 32, n_out / 32), dim3(256), 0, stream, W, h->tscratch, n_out, IEF_D);
+        HIP_TRY(hipGetLastError());
+        return launch_split_planes(h->tscratch, *dst, (size_t)n_out * D, stream);
+    };
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l < L; ++l) {
+            if (int rc = tsplit(&h->in_wst[m][l], h->in_w[m][l], 3 * IEF_D)) return rc;
+            if (int rc = tsplit(&h->out_wst[m][l], h->out_w[m][l], IEF_D)) return rc;
+        }
+        if (int rc = tsplit(&h->head_wst[m], h->head_w[m], 2 * IEF_D)) return rc;
+    }
+    for (int k = 0; k < K; ++k) {
+        if (int rc = tsplit(&h->ref_w1st[k], h->ref_w1[k], IEF_D)) return rc;
+        if (int rc = tsplit(&h->ref_w2st[k], h->ref_w2[k], IEF_D)) return rc;
+    }
+    h->tplanes_valid = true;
+    return 0;
+}
+
 // dX[rows, n_in] = alpha * dY[rows, n_out] * W[n_out, n_in] (+ R) (gated by G): the input gradient of a Linear whose weight is stored
-// [out, in] as torch stores it
-static int launch_dx(const float* dY, int ldy, const float* W, int n_out, int n_in, float* dX, const float* R, const float* G, float alpha,
-                     int rows, hipStream_t stream) {
+// [out, in] as torch stores it.  `planes_t` (bf16x6 handles, full grids): the same product on the split kernel.
+static int launch_dx(iefvad_handle* h, const bf16_t* planes_t, const float* dY, int ldy, const float* W, int n_out, int n_in, float* dX,
+                     const float* R, const float* G, float alpha, int rows, hipStream_t stream) {
+    if (planes_t && n_in == IEF_D && ldy == n_out && split_eligible(rows, IEF_D, n_out, 1) && (!R || !G) && (G || alpha == 1.f)) {
+        GemmBArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = rows; g.N = IEF_D; g.K = n_out; g.lda = n_out; g.ldc = IEF_D; g.alpha = alpha;
+        g.epi = G ? EPI_GATE : (R ? EPI_BIAS_RESID : EPI_BIAS);
+        g.wplane = IEF_D * n_out * 2;
+        g.p[0].A = (const bf16_t*)dY;            // fp32 data behind the typed pointer
+        g.p[0].W = planes_t; g.p[0].bias = h->zero_bias; g.p[0].C = dX; g.p[0].R = G ? G : R;
+        Timer tm;
+        return launch_gemm_split(g, 1, stream, tm, ST_REFINE);
+    }
     BgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = dY; a.B = W; a.C = dX; a.R = R; a.G = G;
     a.M = rows; a.N = n_in; a.K = n_out; a.lda = ldy; a.ldb = n_in; a.ldc = n_in; a.nz2 = 1; a.alpha = alpha;
+    (void)h;
     return launch_bgemm(a, true, false, 1, stream);
 }
 
@@ -385,6 +433,8 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
     float* rpart = ws + t.rpart;
     float* g = ws + t.g;
     float* da = ws + t.da;
+    if (int rc = ensure_train_planes(h, stream)) return rc;
+    const bool tp = h->cfg.compute == IEFVAD_COMPUTE_BF16X6 && h->tplanes_valid;      // dX on the split kernel where the grid fills it
 
     // classifier (imf_vad.py:150)
     {
@@ -405,11 +455,11 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         if (int rc = launch_dw(g, IEF_D, IEF_D, ws + t.hid[k], dw->ref_w2[k], nullptr, 0, nl, rows, part, t.part_floats, stream)) return rc;
         if (int rc = launch_db(g, IEF_D, IEF_D, dw->ref_b2[k], nullptr, 0, nl, rows, cpart, stream)) return rc;
         // d a = (-lambda g W2) gated by h > 0  (ReLU backward on the saved activation)
-        if (int rc = launch_dx(g, IEF_D, h->ref_w2[k], IEF_D, IEF_D, da, nullptr, ws + t.hid[k], nl, rows, stream)) return rc;
+        if (int rc = launch_dx(h, tp ? h->ref_w2st[k] : nullptr, g, IEF_D, h->ref_w2[k], IEF_D, IEF_D, da, nullptr, ws + t.hid[k], nl, rows, stream)) return rc;
         if (int rc = launch_dw(da, IEF_D, IEF_D, ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream)) return rc;
         if (int rc = launch_db(da, IEF_D, IEF_D, dw->ref_b1[k], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
         // d z_k = g + d a W1   (in place: every element of g is read by the thread that overwrites it)
-        if (int rc = launch_dx(da, IEF_D, h->ref_w1[k], IEF_D, IEF_D, g, g, nullptr, 1.f, rows, stream)) return rc;
+        if (int rc = launch_dx(h, tp ? h->ref_w1st[k] : nullptr, da, IEF_D, h->ref_w1[k], IEF_D, IEF_D, g, g, nullptr, 1.f, rows, stream)) return rc;
     }
     // fusion (imf_vad.py:130-144) -> d mu | d logvar of both modalities, stacked
     {
@@ -431,7 +481,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         if (int rc = launch_dw(dhm, 2 * IEF_D, 2 * IEF_D, ws + t.E[m], dw->mu_w[m], dw->logvar_w[m], IEF_D, 1.f, rows, part, t.part_floats, stream))
             return rc;
         if (int rc = launch_db(dhm, 2 * IEF_D, 2 * IEF_D, dw->mu_b[m], dw->logvar_b[m], IEF_D, 1.f, rows, cpart, stream)) return rc;
-        if (int rc = launch_dx(dhm, 2 * IEF_D, h->head_w[m], 2 * IEF_D, IEF_D, gx, nullptr, nullptr, 1.f, rows, stream)) return rc;
+        if (int rc = launch_dx(h, tp ? h->head_wst[m] : nullptr, dhm, 2 * IEF_D, h->head_w[m], 2 * IEF_D, IEF_D, gx, nullptr, nullptr, 1.f, rows, stream)) return rc;
         // whitening LayerNorm (imf_vad.py:117,123), then the layers last to first
         auto ln_bwd = [&](const float* x, const float* gamma, float* dgamma, float* dbeta) -> int {
             LnBwdArgs la;
@@ -459,7 +509,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             const float* Pd = rec->drop[m][l] ? ws + t.Pd[m][l] : P;
             if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream)) return rc;
             if (int rc = launch_db(gx, IEF_D, IEF_D, dw->out_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
-            if (int rc = launch_dx(gx, IEF_D, h->out_w[m][l], IEF_D, IEF_D, datt, nullptr, nullptr, 1.f, rows, stream)) return rc;
+            if (int rc = launch_dx(h, tp ? h->out_wst[m][l] : nullptr, gx, IEF_D, h->out_w[m][l], IEF_D, IEF_D, datt, nullptr, nullptr, 1.f, rows, stream)) return rc;
             const long long sQ = (long long)IEF_T * 3 * IEF_D, sP1 = (long long)IEF_H * IEF_T * IEF_T, sP2 = (long long)IEF_T * IEF_T,
                             sA = (long long)IEF_T * IEF_D;
             BgemmArgs a;
@@ -499,7 +549,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             if (int rc = launch_db(dqkv, 3 * IEF_D, 3 * IEF_D, dw->in_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
             // d x_l = d s_l (residual) + d qkv W_in; the input features need no gradient
             if (l > 0)
-                if (int rc = launch_dx(dqkv, 3 * IEF_D, h->in_w[m][l], 3 * IEF_D, IEF_D, gx, gx, nullptr, 1.f, rows, stream)) return rc;
+                if (int rc = launch_dx(h, tp ? h->in_wst[m][l] : nullptr, dqkv, 3 * IEF_D, h->in_w[m][l], 3 * IEF_D, IEF_D, gx, gx, nullptr, 1.f, rows, stream)) return rc;
         }
     }
     return 0;

@@ -94,6 +94,37 @@ def test_gradients_bf16x6_forward_arithmetic_meets_the_same_gate():
         assert (np.abs(got[g[f"g{i}_idx"]] - want) <= 1e-4 * np.abs(want) + 1e-6 * mx).all(), n
 
 
+def test_bf16x6_backward_on_the_split_kernel_at_a_batch_that_fills_its_grid():
+    """B = 8 (2048 rows, 96 workgroups >= the 72 of the dispatch): in compute='bf16x6' the forward projections AND the backward's
+    input-gradient products (dX = dY W, on three-plane splits of W^T; train.h `launch_dx`) run on the exact-split kernel.  Every
+    parameter gradient against fp64 autograd through the oracle (itself pinned by the grad_*.npz fixtures at B = 3), the same
+    gate as the fixtures'; the f32 handle at the same size alongside, whose bits must differ (another arithmetic ran)."""
+    from oracle import iefvad_oracle as orc
+    L, K, B = 2, 2, 8
+    img, ev, _, _ = synth.make_train_batch(77, B)
+
+    def scalar(o):
+        return o["logits"].sum() + 0.5 * (o["image_mu"] * o["event_logvar"]).sum() + 0.25 * (o["event_mu"] * o["image_logvar"]).sum()
+
+    grads = {}
+    for compute in ("f32", "bf16x6"):
+        model, sd = make_model(5, L, K, "StudentT", 8, compute, 0.0)
+        model.train()
+        scalar(model(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)).backward()
+        grads[compute] = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    scalar(orc.forward(sd64, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_layers=L, num_refinement_steps=K, nu=8),
+                       dtype=torch.float64)).backward()
+    differ = 0
+    for n, want in ((k, v.grad) for k, v in sd64.items()):
+        mx = float(want.abs().max())
+        for compute in ("f32", "bf16x6"):
+            err = (grads[compute][n] - want).abs()
+            assert bool((err <= 1e-4 * want.abs() + 2e-6 * mx).all()), (compute, n, float(err.max()), mx)
+        differ += int(not torch.equal(grads["f32"][n], grads["bf16x6"][n]))
+    assert differ > len(sd64) // 2
+
+
 def test_gradients_are_bit_reproducible_and_accumulate():
     """No atomics in any reduction: two runs give the same bits; a second backward into existing .grad accumulates, as autograd does."""
     _, m1, _, _ = run_case("k2_student8")
