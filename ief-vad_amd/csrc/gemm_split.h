@@ -157,6 +157,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
         tn = grp * pn + (rem - tm * pn);
     }
     const int m0 = tm * GS_BM, n0 = tn * BN;
+#ifdef GS_EXPERIMENT_A_ALIAS      // tools/gemm_tune_split_alias: every row panel reads one of GS_EXPERIMENT_A_ALIAS panels (A L2-resident)
+    const int m0a = (tm % GS_EXPERIMENT_A_ALIAS) * GS_BM;
+#else
+    const int m0a = m0;
+#endif
     const int K = args.K, lda = args.lda;
     const int wplane = args.wplane;                    // bytes between the planes of W
     float ascale = 1.0f, cscale = 1.0f;                // fp16x3: operand scale of A, inverse of both scales
@@ -179,7 +184,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     // A: one instruction = 8 rows x 128 B; wave w, instruction j -> rows 32 w + 8 j + (lane >> 3), chunk lane & 7
     // W: one instruction = 16 rows x 64 B; wave w, plane p, instruction j -> rows WROWS w + 16 j + (lane >> 2), chunk lane & 3
     const int nrecA = (int)((GS_BM - 1) * lda + K) * 4, nrecW = (NP - 1) * wplane + (int)((BN - 1) * K + K) * 2;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0, nrecA, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0a * lda * 4), 0, nrecA, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0, nrecW, 0x00020000);
     const int arow = lane >> 3, achk = lane & 7;
     int voA[2];                                        // row bit 3 = j & 1 enters the swizzle
@@ -282,7 +287,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmBArgs& args, float* sm
     for (int kt = 0; kt < nk; ++kt) {
         const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.W + (size_t)n0 * K * 2), 0,
                                                           (kt + 1 < nk) ? nrecW : 0, 0x00020000);
-        const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0 * lda * 4), 0,
+        const auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)m0a * lda * 4), 0,
                                                           (kt + 2 < nk) ? nrecA : 0, 0x00020000);
         float* Wd = smem + W_BASE + ((kt + 1) & 1) * W_SLOT + uwave * WROWS * 16;
         float* Ad = smem + (kt & 1) * GS_A_SLOT + uwave * 32 * 32;
