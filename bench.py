@@ -382,6 +382,23 @@ def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=
                        f"iefvad_forward_videos calls of >= {batch_chunks} chunks, round-robin on {lanes} HIP streams",
            "videos": nvid, "snippets": total, "chunk_rows": chunks * T, "compute": compute, "snippets_per_s": total / dt,
            "seconds": dt, "seconds_all_passes": dts, "lists": {}}
+    wire_scores = None
+    if compute == "bf16":
+        # the throughput mode's down-conversion on the wire (include/iefvad.h `wire_dtype`): the gather threads round the
+        # fp32 rows to bf16 while staging, half the bytes cross PCIe.  Reported BESIDE the fp32-wire figure above, never as it.
+        harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes, wire_bf16=True)
+        torch.cuda.synchronize()
+        wdts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            wire_scores, _, _, _ = harness.score_loader(model, items, T, dev, "ucfcrime", batch_chunks=batch_chunks, lanes=lanes, wire_bf16=True)
+            torch.cuda.synchronize()
+            wdts.append(time.perf_counter() - t0)
+        wdt = sorted(wdts)[len(wdts) // 2]
+        out["bf16_wire"] = {"what": "same list, fp32 host rows rounded to bf16 by the staging threads (wire_dtype = BF16): 3,072 B per snippet "
+                                    "over PCIe instead of 6,144",
+                            "snippets_per_s": total / wdt, "seconds": wdt, "seconds_all_passes": wdts,
+                            "max_abs_score_diff_vs_fp32_wire": float(max(np.abs(x - y).max() for x, y in zip(wire_scores, scores)))}
     for (dataset, lengths, classes, gt, seed, normal_keys), (lo_i, hi_i) in zip(parts, bounds):
         res = harness.evaluate_scores(scores[lo_i:hi_i], classes, gt, dataset, verbose=False, normal_keys=normal_keys)
         out["lists"][dataset] = {"videos": hi_i - lo_i, "snippets": int(np.sum(lengths)), "auc": res["roc"], "ap": res["ap"],
@@ -412,19 +429,33 @@ def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=
         "abs_auc_diff": abs(roc_auc_score(gt_sub, np.repeat(g_cat, 16)) - roc_auc_score(gt_sub, np.repeat(c_cat, 16))),
         "abs_ap_diff": abs(average_precision_score(gt_sub, np.repeat(g_cat, 16)) - average_precision_score(gt_sub, np.repeat(c_cat, 16)))}
     out["x_cpu_oracle"] = out["snippets_per_s"] / (nsub / t_cpu)
+    if wire_scores is not None:
+        w_cat = np.concatenate([wire_scores[i] for i in picked])
+        out["bf16_wire"]["vs_fp32_cpu_oracle_on_sample"] = {
+            "max_abs_score_diff": float(np.abs(w_cat - c_cat).max()),
+            "abs_auc_diff": abs(roc_auc_score(gt_sub, np.repeat(w_cat, 16)) - roc_auc_score(gt_sub, np.repeat(c_cat, 16))),
+            "abs_ap_diff": abs(average_precision_score(gt_sub, np.repeat(w_cat, 16)) - average_precision_score(gt_sub, np.repeat(c_cat, 16)))}
     return out
 
 
 def train_step_block(dev, a, chunks=128, steps=4):
+    """Both arithmetic modes of the training path: the headline's (bf16x6: forward projections and the backward's input-gradient
+    products on the exact-split kernel, weight gradients on the fp32 MFMA kernel) first, fp32 MFMA throughout beside it."""
+    out = train_step_one(dev, a, "bf16x6", chunks, steps)
+    out["f32_mode"] = train_step_one(dev, a, "f32", chunks, steps)
+    return out
+
+
+def train_step_one(dev, a, compute, chunks=128, steps=4):
     """whole training steps of the reference's UCF configuration (train/ucf_train.py:43-106 with main.py's defaults:
     2 x batch_size 64 = 128 chunks of [256, 768], K = 10, StudentT nu = 8, attention dropout 0.1, AdamW lr 2e-5) on this GPU:
-    train-mode forward, CLAS2 + regulariser + KL, backward of the loss head and of the model, AdamW -- all in libiefvad (fp32 MFMA).
+    train-mode forward, CLAS2 + regulariser + KL, backward of the loss head and of the model, AdamW -- all in libiefvad.
     Algorithmic FLOPs per step = 3 x the forward's 50.33 MFLOP per snippet."""
     import torch
     import iefvad_amd
     from iefvad_amd import losses, synth, trainer
     margs = argparse.Namespace(visual_layers=L, visual_head=H, num_refinement_steps=K_STEPS, lambda_ref=0.5, noise_model="StudentT", nu=8)
-    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, compute="f32")
+    model = iefvad_amd.MMFMIL(14, D, T, D, H, L, 8, 10, 10, "cuda", margs, compute=compute)
     model.load_state_dict(synth.make_state_dict(0, D, L, K_STEPS))
     model = model.to(dev).train()
     opt = losses.AdamW(model.parameters(), lr=2e-5)
@@ -445,7 +476,7 @@ def train_step_block(dev, a, chunks=128, steps=4):
     dt = (time.perf_counter() - t0) / steps
     flops = 3 * TOTAL_FLOPS_PER_SNIPPET * chunks * T
     return {"workload": f"training step, {chunks} chunks x {T} x {D} (ucf_train.py: 2 x batch_size 64), K={K_STEPS}, L={L}, StudentT, attention "
-                        f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute=f32",
+                        f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute={compute}",
             "snippets_per_s": chunks * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_tflop_per_step": flops / 1e12,
             "achieved_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "loss_total": float(terms["total"])}

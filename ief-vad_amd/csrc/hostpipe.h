@@ -21,6 +21,46 @@
 #include <condition_variable>
 #include <mutex>
 
+// fp32 -> bf16 (round to nearest even, NaN -> quiet NaN with its sign: what the device's v_cvt_pk_bf16_f32 gives) with non-temporal
+// stores: the staging form of wire_dtype = BF16 (include/iefvad.h).  n_src bytes of fp32 in, n_src / 2 bytes out; the caller keeps
+// ranges at multiples of 64 source bytes.
+#define IEF_CONVERT_BODY                                                                                                     \
+    typedef unsigned u8v __attribute__((vector_size(32)));                                                                   \
+    typedef unsigned u8vu __attribute__((vector_size(32), aligned(1)));                                                      \
+    typedef int i8v __attribute__((vector_size(32)));                                                                        \
+    typedef unsigned short h8v __attribute__((vector_size(16)));                                                             \
+    typedef unsigned short h16v __attribute__((vector_size(32)));                                                            \
+    size_t i = 0;                                                                                                            \
+    if (((uintptr_t)d & 31) == 0) {                                                                                          \
+        for (; i + 64 <= n_src; i += 64) {                                                                                   \
+            h8v half[2];                                                                                                     \
+            for (int q = 0; q < 2; ++q) {                                                                                    \
+                const u8v u = *(const u8vu*)(s + i + 32 * q);                                                                \
+                const u8v r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                                                        \
+                const i8v isnan = (i8v)((u & 0x7FFFFFFFu) > 0x7F800000u);                                                    \
+                const u8v o = ((u8v)isnan & ((u >> 16) | 0x40u)) | (~(u8v)isnan & r);                                        \
+                half[q] = __builtin_convertvector(o, h8v);                                                                   \
+            }                                                                                                                \
+            const h16v both = __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
+            __builtin_nontemporal_store(both, (h16v*)(d + i / 2));                                                           \
+        }                                                                                                                    \
+    }                                                                                                                        \
+    for (; i + 4 <= n_src; i += 4) {                                                                                         \
+        unsigned u;                                                                                                          \
+        memcpy(&u, s + i, 4);                                                                                                \
+        const unsigned short o = ((u & 0x7FFFFFFFu) > 0x7F800000u) ? (unsigned short)((u >> 16) | 0x40u)                      \
+                                                                   : (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); \
+        memcpy(d + i / 2, &o, 2);                                                                                            \
+    }
+__attribute__((target("avx2"))) static void stream_convert_bf16_avx2(char* d, const char* s, size_t n_src) { IEF_CONVERT_BODY }
+static void stream_convert_bf16_base(char* d, const char* s, size_t n_src) { IEF_CONVERT_BODY }
+#undef IEF_CONVERT_BODY
+static void stream_convert_bf16(char* d, const char* s, size_t n_src) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) stream_convert_bf16_avx2(d, s, n_src);
+    else stream_convert_bf16_base(d, s, n_src);
+}
+
 // A few persistent copy threads: a job is one byte stream (the concatenation of `count` pieces) cut into equal byte ranges, one per
 // thread -- a range may start and end inside a piece, so short and long videos balance.  Threads sleep between jobs.
 struct GatherPool {
@@ -33,18 +73,23 @@ struct GatherPool {
     // the job
     char* dst = nullptr;
     const void* const* srcs = nullptr;
-    const size_t* offs = nullptr;        // count + 1 prefix sums of the piece sizes
+    const size_t* offs = nullptr;        // count + 1 prefix sums of the piece sizes (SOURCE bytes)
     int64_t count = 0;
+    bool to_bf16 = false;                // the pieces are fp32, the destination takes them as bf16 (half the bytes)
 
     void work(int t, int nt) {
         const size_t total = offs[count];
-        const size_t lo = total / nt * t, hi = (t == nt - 1) ? total : total / nt * (t + 1);
+        const size_t step = (total / nt) & ~(size_t)63;      // ranges start at multiples of 64 source bytes (16 fp32 -> one 32-byte store)
+        const size_t lo = step * t, hi = (t == nt - 1) ? total : step * (t + 1);
         if (hi <= lo) return;
         int64_t i = (int64_t)(std::upper_bound(offs, offs + count + 1, lo) - offs) - 1;      // piece that holds byte lo
         size_t pos = lo;
         while (pos < hi) {
             const size_t end = offs[i + 1] < hi ? offs[i + 1] : hi;
-            if (end > pos) stream_copy(dst + pos, (const char*)srcs[i] + (pos - offs[i]), end - pos);
+            if (end > pos) {
+                if (to_bf16) stream_convert_bf16(dst + pos / 2, (const char*)srcs[i] + (pos - offs[i]), end - pos);
+                else stream_copy(dst + pos, (const char*)srcs[i] + (pos - offs[i]), end - pos);
+            }
             pos = end;
             ++i;
         }
@@ -67,8 +112,8 @@ struct GatherPool {
         }
     }
     // called by ONE thread at a time; the caller copies range 0 itself
-    void run(char* dst_, const void* const* srcs_, const size_t* offs_, int64_t count_) {
-        dst = dst_; srcs = srcs_; offs = offs_; count = count_;
+    void run(char* dst_, const void* const* srcs_, const size_t* offs_, int64_t count_, bool to_bf16_ = false) {
+        dst = dst_; srcs = srcs_; offs = offs_; count = count_; to_bf16 = to_bf16_;
         const size_t total = offs_[count_];
         if (threads.empty() || total < ((size_t)1 << 20)) { work(0, 1); return; }
         {
@@ -175,20 +220,48 @@ static void host_gather_run(char* dst, const void* const* srcs, const size_t* nb
     for (auto& th : pool) th.join();
 }
 
+// the staging form of wire_dtype = BF16 as an entry of its own (what the copy threads of the list walk run): fp32 pieces in, one
+// contiguous bf16 stream out
+extern "C" int iefvad_host_gather_bf16(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
+    if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather_bf16: null argument");
+    if (count == 0) return 0;
+    for (int64_t i = 0; i < count; ++i) {
+        if (nbytes[i] && !srcs[i]) return fail("iefvad_host_gather_bf16: srcs[%lld] is null", (long long)i);
+        if (nbytes[i] % 64) return fail("iefvad_host_gather_bf16: nbytes[%lld] = %zu is not a multiple of 64 (16 fp32 values)", (long long)i, nbytes[i]);
+    }
+    try {
+        std::vector<size_t> off((size_t)count + 1);
+        off[0] = 0;
+        for (int64_t i = 0; i < count; ++i) off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
+        GatherPool pool;
+        pool.start(threads < 1 ? 1 : (threads > 16 ? 16 : threads));
+        pool.run((char*)dst, srcs, off.data(), count, true);
+    } catch (const std::exception& e) {
+        return fail("iefvad_host_gather_bf16: %s", e.what());
+    }
+    return 0;
+}
+
 extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, const void* const* ev_rows, int32_t in_dtype,
-                                          const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
+                                          int32_t wire_dtype, const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
                                           int32_t host_threads, float* logits, float* w_i_mean, float* w_e_mean, void* stream_) {
     if (!h || !img_rows || !ev_rows || !lengths || !logits) return fail("iefvad_forward_videos_host: null argument");
     if (!h->weights_set) return fail("iefvad_forward_videos_host: weights not set");
     if (nvideos <= 0) return fail("iefvad_forward_videos_host: nvideos must be positive (got %d)", nvideos);
     if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
         return fail("iefvad_forward_videos_host: unknown in_dtype %d", in_dtype);
+    if (wire_dtype != in_dtype && !(in_dtype == IEFVAD_IN_F32 && wire_dtype == IEFVAD_IN_BF16))
+        return fail("iefvad_forward_videos_host: wire_dtype %d with in_dtype %d (the wire type is in_dtype, or BF16 for F32 rows)", wire_dtype, in_dtype);
+    if (wire_dtype != in_dtype && h->cfg.compute != IEFVAD_COMPUTE_BF16)
+        return fail("iefvad_forward_videos_host: a narrowed wire type belongs to the bf16 mode (compute = %d)", h->cfg.compute);
     for (int v = 0; v < nvideos; ++v) {
         if (lengths[v] <= 0) return fail("iefvad_forward_videos_host: lengths[%d] = %d", v, lengths[v]);
         if (!img_rows[v] || !ev_rows[v]) return fail("iefvad_forward_videos_host: null row pointer (video %d)", v);
     }
     hipStream_t stream = (hipStream_t)stream_;
-    const size_t esz = in_elem_bytes(in_dtype), row_bytes = (size_t)IEF_D * esz;
+    const bool narrow = wire_dtype != in_dtype;
+    const size_t row_bytes = (size_t)IEF_D * in_elem_bytes(in_dtype);            // host rows
+    const size_t wire_row_bytes = (size_t)IEF_D * in_elem_bytes(wire_dtype);     // staging slots, copies, device input slots
     const int want = batch_chunks > 0 ? batch_chunks : 128;
     try {
 
@@ -238,7 +311,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         }
     }
     HostPipe& p = *h->hostpipe;
-    const size_t need_slot = (size_t)max_rows * row_bytes;
+    const size_t need_slot = (size_t)max_rows * wire_row_bytes;
     if (p.slot_bytes < need_slot) {
         for (int s = 0; s < HostPipe::kSlots; ++s) {       // nothing may still be reading the old slots
             HIP_TRY(hipEventSynchronize(p.sent[s]));
@@ -296,7 +369,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         for (int i = 0; i < n; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + (size_t)lengths[b.v0 + i] * row_bytes;
         for (int m = 0; m < 2; ++m) {
             for (int i = 0; i < n; ++i) srcs[(size_t)i] = (m ? ev_rows : img_rows)[b.v0 + i];
-            p.pool->run((char*)p.pinned[s][m], srcs.data(), offs.data(), n);
+            p.pool->run((char*)p.pinned[s][m], srcs.data(), offs.data(), n, narrow);
         }
     };
     std::thread worker;
@@ -344,7 +417,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
             stage(k);
         }
         const double t1 = trace ? now_us() : 0.0;
-        const size_t bytes = (size_t)b.rows * row_bytes;
+        const size_t bytes = (size_t)b.rows * wire_row_bytes;
         he = hipStreamWaitEvent(p.copy_stream, p.used[s], 0);    // the forward of batch k - 2 has read dev_in[s]
         for (int m = 0; m < 2 && he == hipSuccess; ++m)
             he = hipMemcpyAsync(p.dev_in[s][m], p.pinned[s][m], bytes, hipMemcpyHostToDevice, p.copy_stream);
@@ -360,7 +433,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         hipStream_t cs = p.lane[ln];
         he = hipStreamWaitEvent(cs, p.sent[s], 0);
         if (he != hipSuccess) break;
-        rc = forward_videos_impl(h, p.dev_in[s][0], p.dev_in[s][1], in_dtype, lengths + b.v0, b.v1 - b.v0, nan_to_num,
+        rc = forward_videos_impl(h, p.dev_in[s][0], p.dev_in[s][1], wire_dtype, lengths + b.v0, b.v1 - b.v0, nan_to_num,
                                  p.workspace[ln], p.workspace_bytes, logits + row0, w_i_mean ? w_i_mean + row0 : nullptr,
                                  w_e_mean ? w_e_mean + row0 : nullptr, cs, tm);
         if (rc == 0) he = hipEventRecord(p.used[s], cs);

@@ -355,7 +355,7 @@ class _RowStager:
 
 def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, dataset: str = 'ucfcrime',
                  label_map=None, batch_chunks: int = 0, skip_empty_chunks: bool = True, lanes: int = 1,
-                 ragged: Optional[bool] = None, host_list: bool = True, host_list_bytes: int = 1 << 30):
+                 ragged: Optional[bool] = None, host_list: bool = True, host_list_bytes: int = 1 << 30, wire_bf16: bool = False):
     """Per-video sigmoid scores and mean fusion weights, in loader order.
 
     batch_chunks == 0: one forward per video with B = that video's chunk count -- the reference's call
@@ -372,6 +372,8 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
     `host_list` (default; ragged mode with host-resident loader tensors): the walk over the list happens inside the library
     (`iefvad_forward_videos_host`): Python hands over each video's tensor and length, the library packs, stages, sends and scores
     pass by pass with its own worker thread and copy stream -- one call per `host_list_bytes` of features.  `lanes` is not used then.
+    `wire_bf16` (list path, fp32 features, a compute="bf16" model): the rows are rounded to bf16 while they are staged and half the
+    bytes cross PCIe (`MMFMIL.forward_videos_host(wire_dtype=torch.bfloat16)`); off by default.
 
     lanes > 1 (HIP devices, `iefvad_amd.MMFMIL`): consecutive forwards go round-robin to `lanes` HIP streams, each with a
     lane of the model (`MMFMIL.lanes`: same parameters, own library handle and workspace) and its own pinned staging.
@@ -501,8 +503,9 @@ def score_loader(model: Callable, test_loader: Iterable, maxlen: int, device, da
             nonlocal group, gbytes, total
             if not group:
                 return
+            wire = torch.bfloat16 if (wire_bf16 and group[0][0].dtype == torch.float32) else None
             out = model.forward_videos_host([g[0] for g in group], [g[1] for g in group], [g[2] for g in group], nan_to_num=True,
-                                            batch_chunks=batch_chunks)
+                                            batch_chunks=batch_chunks, wire_dtype=wire)
             dev_prob.append(out['logits'])
             dev_wi.append(out['w_i_mean'])
             dev_we.append(out['w_e_mean'])

@@ -428,13 +428,15 @@ class MMFMIL(nn.Module):
             return {k: res[k] for k in OUTPUT_KEYS}   # the reference's key order
         return res
 
-    def forward_videos_host(self, imgs, evs, lengths, nan_to_num: bool = True, batch_chunks: int = 128, host_threads: int = 0
-                            ) -> Dict[str, torch.Tensor]:
+    def forward_videos_host(self, imgs, evs, lengths, nan_to_num: bool = True, batch_chunks: int = 128, host_threads: int = 0,
+                            wire_dtype: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
         """A whole list of videos in ONE library call (`iefvad_forward_videos_host`): `imgs[v]`, `evs[v]` are contiguous HOST tensors
         of one dtype whose first `lengths[v]` rows ([..., D]) are video v's features -- e.g. the padded tensors a DataLoader
         delivers (data/dataset.py:34-52).  The library packs whole videos into passes of >= `batch_chunks` chunks, stages and sends
         pass k + 1 while pass k computes, and returns DEVICE vectors `logits`, `w_i_mean`, `w_e_mean` of [sum(lengths)] in list
-        order (stream-ordered on the current stream).  Same results as `forward_videos` on the same batches."""
+        order (stream-ordered on the current stream).  Same results as `forward_videos` on the same batches.
+        `wire_dtype=torch.bfloat16` (fp32 features, compute="bf16" only): the gather threads round the rows to bf16 while staging, so
+        half the bytes cross PCIe; same results as `forward_videos` on `rows.to(torch.bfloat16)` (include/iefvad.h)."""
         if self.training:
             raise RuntimeError("iefvad_amd.MMFMIL.forward_videos_host is an evaluation entry point; call model.eval() first")
         self._noise_code()
@@ -445,6 +447,9 @@ class MMFMIL(nn.Module):
         D = self.temporal.embed_dim
         if dt not in _IN_DTYPES:
             raise ValueError(f"feature dtype {dt} is not supported by the list entry (fp32, fp16 or bf16)")
+        wire = dt if wire_dtype is None else wire_dtype
+        if wire not in _IN_DTYPES:
+            raise ValueError(f"wire dtype {wire} is not supported (the feature dtype, or torch.bfloat16 for fp32 features)")
         n = len(lens)
         # validation as C-speed sweeps (a per-video Python loop costs more than the library call on lists of short videos)
         for parts in (imgs, evs):
@@ -465,7 +470,7 @@ class MMFMIL(nn.Module):
             self._ensure_weights(device, stream)
             f32 = dict(dtype=torch.float32, device=device)
             res = {"logits": torch.empty(total, **f32), "w_i_mean": torch.empty(total, **f32), "w_e_mean": torch.empty(total, **f32)}
-            rc = lib.iefvad_forward_videos_host(self._handle, pi, pe, _IN_DTYPES[dt], larr, n, 1 if nan_to_num else 0, int(batch_chunks),
+            rc = lib.iefvad_forward_videos_host(self._handle, pi, pe, _IN_DTYPES[dt], _IN_DTYPES[wire], larr, n, 1 if nan_to_num else 0, int(batch_chunks),
                                                 int(host_threads), C.c_void_p(res["logits"].data_ptr()),
                                                 C.c_void_p(res["w_i_mean"].data_ptr()), C.c_void_p(res["w_e_mean"].data_ptr()),
                                                 C.c_void_p(stream))

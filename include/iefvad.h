@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 5
+#define IEFVAD_ABI_VERSION 6
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -190,12 +190,18 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
  * internal copy stream and enqueues its forward on `stream`; results land in list order.
  *   img_rows, ev_rows   HOST arrays of nvideos HOST pointers: video v's [lengths[v], D] feature rows of `in_dtype`, contiguous
  *                       (e.g. the first lengths[v] rows of the zero-padded tensor a DataLoader delivers)
+ *   wire_dtype          the element type the rows cross PCIe in: `in_dtype` (the rows as they are), or IEFVAD_IN_BF16 for F32 rows
+ *                       on a BF16-mode handle -- the throughput mode's down-conversion on the wire: the gather
+ *                       threads round to bf16 (nearest even, as the device would) while they stage, half the bytes are copied, and the
+ *                       forward runs as iefvad_forward_videos does on IEFVAD_IN_BF16 rows.  The bf16 mode rounds these rows for its
+ *                       first projection anyway; what changes is the first layer's residual, which reads the rounded row too
+ *                       (and nan_to_num's +-inf replacement is the bf16 extreme).  Other combinations are refused.
  *   logits, w_i_mean, w_e_mean   DEVICE, [sum(lengths)] fp32 each (the means nullable), valid once `stream` has run
  * Returns when every pass has been enqueued and every host row has been read (the caller's host tensors are free again);
  * staging slots, device input slots and the workspace belong to the handle.  Same results as iefvad_forward_videos on the
  * same batches. */
 int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, const void* const* ev_rows, int32_t in_dtype,
-                               const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
+                               int32_t wire_dtype, const int32_t* lengths, int32_t nvideos, int32_t nan_to_num, int32_t batch_chunks,
                                int32_t host_threads, float* logits, float* w_i_mean, float* w_e_mean, void* stream);
 
 /* ---- training-side loss head: forward, and its gradients w.r.t. the model's outputs -----------------
@@ -298,6 +304,10 @@ int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* ex
  * pinned staging buffer that one asynchronous copy then sends to the device as iefvad_forward_videos's img_rows / ev_rows.
  * Pure host code: all pointers are HOST pointers. */
 int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads);
+/* The same gather with the rows narrowed on the way: srcs[i] holds nbytes[i] bytes of fp32 (multiples of 64), dst receives them as
+ * bf16 (sum(nbytes) / 2 bytes; round to nearest even, NaN stays NaN with its sign, overflow to +-inf -- the device's conversion).
+ * This is what iefvad_forward_videos_host's copy threads run for wire_dtype = IEFVAD_IN_BF16. */
+int iefvad_host_gather_bf16(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads);
 
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.

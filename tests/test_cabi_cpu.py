@@ -156,3 +156,48 @@ def test_host_gather_concatenates_rows_without_a_gpu(lib):
     assert np.array_equal(dst[13:-8], np.concatenate(parts)) and (dst[-8:] == 0xEE).all() and (dst[:13] == 0xEE).all()
     assert lib.iefvad_host_gather(None, None, None, 0, 4) == 0
     assert lib.iefvad_host_gather(None, None, None, 3, 4) != 0 and "null" in L.last_error()
+
+
+def test_host_gather_bf16_rounds_as_torch_does(lib):
+    """`iefvad_host_gather_bf16` -- what the list walk's copy threads run for wire_dtype = BF16: fp32 pieces in, one bf16 stream out,
+    bit for bit `torch.Tensor.to(torch.bfloat16)` (round to nearest even) on random bit patterns of every exponent, ties, values
+    that round up to the next binade or to +-inf, denormals, zeros of both signs and infinities; NaNs stay NaNs with their sign.
+    One and many threads (byte ranges that start inside a piece), pieces of uneven size, aligned and misaligned buffers."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(1)
+    special = np.array([0x00000000, 0x80000000, 0x7F800000, 0xFF800000, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F7F8000, 0x7F7F7FFF, 0x3F808000,
+                        0x3F818000, 0x3F80FFFF, 0x3F7FFFFF, 0x00000001, 0x007FFFFF, 0x00008000, 0x00018000, 0x7FC00000, 0xFFC00001,
+                        0x7F800001, 0xFF8ABCDE, 0x7FFFFFFF, 0x3F800000], dtype=np.uint32)
+    for sizes, threads, shift in (([16], 1, 0), ([768 * 37, 768, 768 * 300, 768 * 5], 1, 0), ([768 * 701, 768 * 3, 768 * 1500, 768 * 256], 7, 0),
+                                  ([768 * 400] * 6, 16, 0), ([768 * 90, 768 * 411], 3, 1)):
+        parts = []
+        for n in sizes:
+            bits = rng.integers(0, 1 << 32, n + shift, dtype=np.uint64).astype(np.uint32)
+            bits[shift:shift + min(n, special.size)] = special[:min(n, special.size)]
+            parts.append(bits.view(np.float32)[shift:])                       # shift = 1: sources at 4 mod 32
+        total = sum(sizes)
+        raw = np.full(total + 16 + 16, 0xEEEE, np.uint16)
+        dst = raw[16 * shift:]                                                # shift = 1: destination 32 bytes on (still 32-byte aligned)
+        ptrs = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+        nb = (C.c_size_t * len(parts))(*[4 * n for n in sizes])
+        assert lib.iefvad_host_gather_bf16(dst.ctypes.data, ptrs, nb, len(parts), threads) == 0, L.last_error()
+        src = np.concatenate(parts)
+        want = torch.from_numpy(src.copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+        got = dst[:total]
+        nan = np.isnan(src)
+        assert np.array_equal(got[~nan], want[~nan]), (sizes, threads)
+        assert ((got[nan] & 0x7F80) == 0x7F80).all() and ((got[nan] & 0x007F) != 0).all()            # still NaN ...
+        assert np.array_equal(got[nan] >> 15, src[nan].view(np.uint32) >> 31)                         # ... of the same sign
+        assert (dst[total:total + 16] == 0xEEEE).all()
+    # a destination that is not 32-byte aligned takes the scalar path: same bits
+    src = rng.standard_normal(768 * 3).astype(np.float32)
+    raw = np.zeros(768 * 3 + 32, np.uint16)
+    off = (-(raw.ctypes.data // 2) % 16) + 1                                  # 2 bytes past a 32-byte boundary
+    ptrs = (C.c_void_p * 1)(src.ctypes.data)
+    nb = (C.c_size_t * 1)(src.nbytes)
+    assert lib.iefvad_host_gather_bf16(raw.ctypes.data + 2 * off, ptrs, nb, 1, 2) == 0, L.last_error()
+    assert np.array_equal(raw[off:off + src.size], torch.from_numpy(src).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
+    nb = (C.c_size_t * 1)(100)
+    assert lib.iefvad_host_gather_bf16(raw.ctypes.data, ptrs, nb, 1, 2) != 0 and "multiple of 64" in L.last_error()
+    assert lib.iefvad_host_gather_bf16(None, None, None, 2, 2) != 0 and "null" in L.last_error()

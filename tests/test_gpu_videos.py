@@ -234,6 +234,48 @@ def test_host_list_entry_equals_forward_videos(compute, batch_chunks):
         model.forward_videos_host(padded_i, padded_e[:-1], lengths)
 
 
+def test_host_list_bf16_wire_equals_forward_videos_on_rounded_rows():
+    """`wire_dtype = BF16` (include/iefvad.h; SURVEY 7-2's down-conversion on the wire in the throughput mode): the staging threads
+    round the fp32 rows to bf16 -- nearest even, NaN kept -- so half the bytes cross PCIe.  Bit for bit what `forward_videos` gives on
+    rows torch rounded to bf16 (the same rounding; incl. a video with a NaN under the NaN rule, an -inf, values that round up to the
+    next binade and to +-inf), for pass sizes that split the list at different videos; within the bf16 mode's own gate of the
+    fp32-wire scores; refused for another compute mode or another dtype pair."""
+    lengths = EDGE_LENGTHS + [90, 400, 33, 1300]
+    vids = videos(lengths, seed=29)
+    vids[2][0][3, 5] = np.nan                      # NaN rule: this video's image tensor -> nan_to_num (NaN -> 0, -inf -> lowest)
+    vids[2][0][7, 9] = -np.inf
+    vids[2][0][8, 1] = 3.4e38                      # finite in fp32, +inf once rounded to bf16: replaced under the same rule
+    vids[4][1][0, :4] = [np.float32(1.0) + np.float32(2.0 ** -8), 1.0e-39, -65504.0, np.float32(1.0) - np.float32(2.0 ** -9)]
+    model, _ = make_model("bf16", outputs="scores")
+    padded_i = [torch.from_numpy(harness.process_split(v[0], 256)[0]) for v in vids]
+    padded_e = [torch.from_numpy(harness.process_split(v[1], 256)[0]) for v in vids]
+    img_b = torch.from_numpy(np.concatenate([v[0] for v in vids])).to(torch.bfloat16).cuda()
+    ev_b = torch.from_numpy(np.concatenate([v[1] for v in vids])).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        want = model.forward_videos(img_b, ev_b, lengths)
+    for batch_chunks in (3, 8, 128):
+        got = model.forward_videos_host(padded_i, padded_e, lengths, batch_chunks=batch_chunks, wire_dtype=torch.bfloat16)
+        for k in want:
+            both_nan = torch.isnan(got[k]) & torch.isnan(want[k])      # the replaced +-inf (the bf16 extremes) overflow that chunk's LayerNorm
+            if k == "logits":
+                assert bool(((got[k] == want[k]) | both_nan).all()), (batch_chunks, k, (got[k] - want[k]).abs().nan_to_num().max().item())
+            else:
+                assert float((got[k] - want[k]).abs().nan_to_num().max()) <= 1e-6 and bool((torch.isnan(got[k]) == torch.isnan(want[k])).all()), (batch_chunks, k)
+    assert int(torch.isnan(got["logits"]).sum()) == 256          # video 2 (one chunk of 256 rows), nothing else
+    # against the fp32 wire: the bf16 mode's own accuracy class (the first layer's residual now reads the rounded row)
+    clean = [i for i in range(len(lengths)) if i not in (2, 4)]
+    ref = model.forward_videos_host([padded_i[i] for i in clean], [padded_e[i] for i in clean], [lengths[i] for i in clean])
+    nar = model.forward_videos_host([padded_i[i] for i in clean], [padded_e[i] for i in clean], [lengths[i] for i in clean],
+                                    wire_dtype=torch.bfloat16)
+    d = (torch.sigmoid(ref["logits"]) - torch.sigmoid(nar["logits"])).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 2e-3, (float(d.max()), float(d.mean()))
+    with pytest.raises(RuntimeError, match="wire_dtype"):
+        model.forward_videos_host(padded_i, padded_e, lengths, wire_dtype=torch.float16)
+    f32_model, _ = make_model("f32", outputs="scores")
+    with pytest.raises(RuntimeError, match="bf16 mode"):
+        f32_model.forward_videos_host(padded_i, padded_e, lengths, wire_dtype=torch.bfloat16)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_score_loader_host_list_equals_the_python_loop(dtype):
     """harness.score_loader: the list walk inside the library (host_list=True, the default) against the Python loop around

@@ -29,7 +29,9 @@ def main():
     p.add_argument("--batch-chunks", type=int, default=128)
     p.add_argument("--prelude", default="none", choices=["none", "ucf", "threads"],
                    help="what runs in the process first: bench.ucf_eval (as in a default bench run), or only torch.set_num_threads(host share)")
+    p.add_argument("--wire-bf16", action="store_true", help="round the fp32 rows to bf16 while staging (wire_dtype = BF16)")
     a = p.parse_args()
+    wire = torch.bfloat16 if a.wire_bf16 else None
     dev = torch.device("cuda", 0)
     if a.prelude == "ucf":
         ba = bench.parse([])
@@ -51,12 +53,12 @@ def main():
         model.load_state_dict(synth.make_state_dict(wseed, 768, 2, K))
         model = model.to(dev).eval()
         for _ in range(2):
-            harness.score_loader(model, items, 256, dev, "ucfcrime", batch_chunks=a.batch_chunks)
+            harness.score_loader(model, items, 256, dev, "ucfcrime", batch_chunks=a.batch_chunks, wire_bf16=a.wire_bf16)
         torch.cuda.synchronize()
         whole = []
         for _ in range(5):
             t0 = time.perf_counter()
-            harness.score_loader(model, items, 256, dev, "ucfcrime", batch_chunks=a.batch_chunks)
+            harness.score_loader(model, items, 256, dev, "ucfcrime", batch_chunks=a.batch_chunks, wire_bf16=a.wire_bf16)
             torch.cuda.synchronize()
             whole.append(time.perf_counter() - t0)
         ph = []
@@ -65,7 +67,7 @@ def main():
             un = [harness._unpack_rows(it, 256, "ucfcrime", None) for it in items]
             t1 = time.perf_counter()
             out = model.forward_videos_host([u[0] for u in un], [u[1] for u in un], [u[3] for u in un], batch_chunks=a.batch_chunks,
-                                            host_threads=a.threads)
+                                            host_threads=a.threads, wire_dtype=wire)
             t2 = time.perf_counter()
             torch.cuda.synchronize()
             t3 = time.perf_counter()
@@ -79,7 +81,7 @@ def main():
                           "snippets_per_s": total / med(whole),
                           "phases_ms": {"python_collect": med([x[0] for x in ph]) * 1e3, "library_call": med([x[1] for x in ph]) * 1e3,
                                         "device_wait": med([x[2] for x in ph]) * 1e3, "sigmoid_d2h_split": med([x[3] for x in ph]) * 1e3},
-                          "host_threads": a.threads or "library default", "batch_chunks": a.batch_chunks, "prelude": a.prelude,
+                          "wire": "bf16" if a.wire_bf16 else "fp32", "host_threads": a.threads or "library default", "batch_chunks": a.batch_chunks, "prelude": a.prelude,
                           "torch_threads": torch.get_num_threads()}))
         del model
 
