@@ -68,13 +68,17 @@ python3 "$R/tools/pmc_summary.py" "$O/pmc_sq_cfg5" "$O/pmc_fetch_cfg5" "$O/pmc_w
 echo "[7] packed evaluation loop: where the wall clock goes"
 python3 "$R/tools/ragged_profile.py" > "$O/ragged_profile.log" 2>&1
 echo "[8] training step (ucf_train.py's configuration, B = 128): kernel stats"
-python3 "$R/tools/train_step_probe.py" > "$O/train_step.json" 2> "$O/train_step.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -o t -- python3 "$R/tools/train_step_probe.py" --steps 3 --warmup 1 \
+python3 "$R/tools/train_step_probe.py" --compute bf16x6 > "$O/train_step.json" 2> "$O/train_step.err"
+python3 "$R/tools/train_step_probe.py" --compute f32 >> "$O/train_step.json" 2>> "$O/train_step.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -o t -- python3 "$R/tools/train_step_probe.py" --compute bf16x6 --steps 3 --warmup 1 \
     > "$O/train_step_under_rocprof.json" 2> "$O/trace_train.log"
 python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_train" -name '*kernel_stats.csv' | head -1)" "$O/train_step_kernel_stats.csv" > /dev/null
 echo "[9] the evaluation list walked inside the library: phases of configs 3 and 5"
 IEFVAD_HOSTPIPE_TRACE=1 python3 "$R/tools/host_list_probe.py" > "$O/host_list_probe.log" 2> "$O/host_list_trace.log"
 grep hostpipe "$O/host_list_trace.log" | tail -16 >> "$O/host_list_probe.log"
+echo "== wire_dtype = BF16 (fp32 host rows rounded to bf16 by the staging threads)" >> "$O/host_list_probe.log"
+IEFVAD_HOSTPIPE_TRACE=1 python3 "$R/tools/host_list_probe.py" --wire-bf16 >> "$O/host_list_probe.log" 2> "$O/host_list_trace_wire.log"
+grep hostpipe "$O/host_list_trace_wire.log" | tail -16 >> "$O/host_list_probe.log"
 echo "[10] persistent out_proj + LayerNorm kernel: phase stamps (diag build)"
 if [ -f "$R/build/libiefvad_ocdiag.so" ]; then IEFVAD_LIB="$R/build/libiefvad_ocdiag.so" python3 "$R/tools/outproj_pdiag.py" > "$O/outproj_pchain_phase_stamps.log" 2>&1; fi
 for pz in 1 0; do
