@@ -268,28 +268,40 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
     // passes: runs of whole videos with >= `want` chunks; the FIRST pass is half that (the first forward starts after a short
     // gather + copy) and the last chunks of the list are cut into two halves (what is left when the call returns is the copy
     // and the forward of a half pass).  Finer tapering loses: every pass costs ~0.3 ms of copy / event latency.
-    struct Batch { int v0, v1; long long rows, chunks; };
+    // Row-compressed passes (valid rows + one pad row per chunk) are also closed BEFORE their row set outgrows one round of the
+    // row-block kernels -- one 64-row block per CU (num_cus x 64 rows per 128 chunks asked for): a 129th .. 257th block costs a
+    // second round on 256 CUs, i.e. as much as the first 256.
+    struct Batch { int v0, v1; long long rows, chunks, enc; };
     std::vector<Batch> batches;
     long long max_rows = 0, max_chunks = 0, total_chunks = 0;
     for (int v = 0; v < nvideos; ++v) total_chunks += video_chunks(lengths[v]);
+    const bool compressed = !h->dense_encoder && h->cfg.compute != IEFVAD_COMPUTE_FP16X3;
+    static const bool row_cap_off = [] { const char* v = getenv("IEFVAD_HOSTPIPE_ROWCAP"); return v && v[0] == '0'; }();
+    const long long round_rows = (long long)(h->num_cus > 0 ? h->num_cus : 256) * 64;
+    const long long row_cap = (compressed && !row_cap_off) ? round_rows * ((want + 64) / 128 > 1 ? (want + 64) / 128 : 1) : (1LL << 60);
+    auto enc_rows_of = [](int n) -> long long { return (long long)(n / IEF_T) * IEF_T + (n % IEF_T ? n % IEF_T + 1 : 0); };
     {
-        Batch b = {0, 0, 0, 0};
+        Batch b = {0, 0, 0, 0, 0};
         long long done_chunks = 0;
         long long target = want / 2 > 16 ? want / 2 : want;
+        auto close = [&](int next_v) {
+            batches.push_back(b);
+            if (b.rows > max_rows) max_rows = b.rows;
+            if (b.chunks > max_chunks) max_chunks = b.chunks;
+            done_chunks += b.chunks;
+            b = Batch{next_v, next_v, 0, 0, 0};
+            const long long left = total_chunks - done_chunks;
+            target = want;
+            if (left < want + want / 2 && left > want / 2) target = (left + 1) / 2;
+        };
         for (int v = 0; v < nvideos; ++v) {
+            const long long e = enc_rows_of(lengths[v]);
+            if (b.chunks > 0 && b.enc + e > row_cap && b.enc >= row_cap / 2) close(v);      // the video would start a second round
             b.rows += lengths[v];
             b.chunks += video_chunks(lengths[v]);
+            b.enc += e;
             b.v1 = v + 1;
-            if (b.chunks >= target || v == nvideos - 1) {
-                batches.push_back(b);
-                if (b.rows > max_rows) max_rows = b.rows;
-                if (b.chunks > max_chunks) max_chunks = b.chunks;
-                done_chunks += b.chunks;
-                b = Batch{v + 1, v + 1, 0, 0};
-                const long long left = total_chunks - done_chunks;
-                target = want;
-                if (left < want + want / 2 && left > want / 2) target = (left + 1) / 2;
-            }
+            if (b.chunks >= target || v == nvideos - 1) close(v + 1);
         }
     }
     if (max_chunks > 0x7fffffffLL / IEF_T) return fail("iefvad_forward_videos_host: batch too large");

@@ -234,6 +234,27 @@ def test_host_list_entry_equals_forward_videos(compute, batch_chunks):
         model.forward_videos_host(padded_i, padded_e[:-1], lengths)
 
 
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_host_list_passes_closed_at_one_round_of_row_blocks(compute):
+    """A list long enough (31 k rows, 140 chunks) that the walk closes passes by ROWS: a row-compressed pass stops before its row set
+    outgrows one 64-row block per CU (csrc/hostpipe.h), so the cuts fall at other videos than the chunk count alone would put them.
+    Same results as one `forward_videos` call over all rows (bit for bit: f32 is batch-size invariant, the bf16 row-block and ring
+    kernels agree with each other)."""
+    rng = np.random.default_rng(5)
+    lengths = [int(n) for n in rng.integers(300, 1100, 45)]
+    vids = videos(lengths, seed=31)
+    model, _ = make_model(compute, outputs="scores")
+    padded_i = [torch.from_numpy(harness.process_split(v[0], 256)[0]) for v in vids]
+    padded_e = [torch.from_numpy(harness.process_split(v[1], 256)[0]) for v in vids]
+    got = model.forward_videos_host(padded_i, padded_e, lengths, batch_chunks=128)
+    want = ragged(model, vids)
+    for k in want:
+        if compute == "bf16" and k != "logits":
+            assert float((got[k] - want[k]).abs().max()) <= 1e-6, k
+        else:
+            assert torch.equal(got[k], want[k]), (k, (got[k] - want[k]).abs().max().item())
+
+
 def test_host_list_bf16_wire_equals_forward_videos_on_rounded_rows():
     """`wire_dtype = BF16` (include/iefvad.h; SURVEY 7-2's down-conversion on the wire in the throughput mode): the staging threads
     round the fp32 rows to bf16 -- nearest even, NaN kept -- so half the bytes cross PCIe.  Bit for bit what `forward_videos` gives on
