@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py"
 QUIET="--no-extra-modes --no-ucf-eval --no-cpu-baseline"
 
-echo "[1] default bench line"; python3 "$B" > "$O/bench_default.json" 2> "$O/bench_default.err"; echo "rc=$?"
+echo "[1] default bench line"; T0=$(date +%s); python3 "$B" > "$O/bench_default.json" 2> "$O/bench_default.err"; echo "rc=$? wall=$(( $(date +%s) - T0 )) s"
 
 for mode in bf16x6 bf16 f32; do
   echo "[2] kernel trace, $mode"
