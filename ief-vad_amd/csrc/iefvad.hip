@@ -789,7 +789,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             // first pass runs, because test.py:90-95 decides per whole video and a video may straddle passes)
 #define RAGGED_IN(T)                                                                                                        \
     do {                                                                                                                    \
-        hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2), dim3(256), 0, stream, (const T*)rg->img_rows,         \
+        hipLaunchKernelGGL(iefvad_scatter_rows_kernel<T>, dim3(nb, 2, IEF_RAGGED_SLICES), dim3(256), 0, stream, (const T*)rg->img_rows,         \
                            (const T*)rg->ev_rows, rg->d_chunks, rg->d_flags, xin[0], xin[1], need_xb0 ? xb[0] : (bf16_t*)nullptr, \
                            need_xb0 ? xb[1] : (bf16_t*)nullptr, enc_rows_mode ? 0 : IEF_T);                                  \
     } while (0)
@@ -1303,11 +1303,11 @@ static int forward_videos_impl(iefvad_handle* h, const void* img_rows, const voi
             const void* pi = (const char*)img_rows + (size_t)r0 * IEF_D * esz;
             const void* pe = (const char*)ev_rows + (size_t)r0 * IEF_D * esz;
             if (in_dtype == IEFVAD_IN_F32)
-                hipLaunchKernelGGL(iefvad_nanflag_kernel<float>, dim3(nb, 2), dim3(256), 0, stream, (const float*)pi, (const float*)pe, dc + c0, (int*)dflags);
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<float>, dim3(nb, 2, IEF_RAGGED_SLICES), dim3(256), 0, stream, (const float*)pi, (const float*)pe, dc + c0, (int*)dflags);
             else if (in_dtype == IEFVAD_IN_F16)
-                hipLaunchKernelGGL(iefvad_nanflag_kernel<__half>, dim3(nb, 2), dim3(256), 0, stream, (const __half*)pi, (const __half*)pe, dc + c0, (int*)dflags);
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<__half>, dim3(nb, 2, IEF_RAGGED_SLICES), dim3(256), 0, stream, (const __half*)pi, (const __half*)pe, dc + c0, (int*)dflags);
             else
-                hipLaunchKernelGGL(iefvad_nanflag_kernel<__hip_bfloat16>, dim3(nb, 2), dim3(256), 0, stream, (const __hip_bfloat16*)pi, (const __hip_bfloat16*)pe, dc + c0, (int*)dflags);
+                hipLaunchKernelGGL(iefvad_nanflag_kernel<__hip_bfloat16>, dim3(nb, 2, IEF_RAGGED_SLICES), dim3(256), 0, stream, (const __hip_bfloat16*)pi, (const __hip_bfloat16*)pe, dc + c0, (int*)dflags);
             for (int j = 0; j < nb; ++j) r0 += hc[c0 + j].valid;
         }
         tm.end(e);

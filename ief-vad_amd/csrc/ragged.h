@@ -30,35 +30,30 @@ template <> struct RaggedLimits<float> { static __device__ float max() { return 
 template <> struct RaggedLimits<__half> { static __device__ float max() { return 65504.f; } };
 template <> struct RaggedLimits<__hip_bfloat16> { static __device__ float max() { return 3.38953139e38f; } };
 
-// one workgroup per (chunk, modality): any NaN among the chunk's valid elements -> flags[2 video + modality] = 1
+// gridDim.z workgroups per (chunk, modality), each scanning every gridDim.z-th 4096-element tile (a pass of 60 - 130 chunks is
+// 120 - 260 workgroups otherwise: a few per CU, each a chain of memory latencies): any NaN among the chunk's valid elements ->
+// flags[2 video + modality] = 1
+#define IEF_RAGGED_SLICES 4
 template <typename T>
 __global__ __launch_bounds__(256) void iefvad_nanflag_kernel(const T* img, const T* ev, const RaggedChunk* chunks, int* flags) {
     const RaggedChunk c = chunks[blockIdx.x];
     const T* src = (blockIdx.y ? ev : img) + (size_t)c.src_row * IEF_D;
-    const int n = c.valid * IEF_D;
+    const int n = c.valid * IEF_D;                     // a multiple of 768, hence of 4
     bool bad = false;
-    int i = threadIdx.x * 4;
-    for (; i + 3 * 1024 < n; i += 4 * 1024) {          // n is a multiple of 768: four 16-byte (8-byte) loads in flight per lane
-        float v[16];
+    for (int base = blockIdx.z * 4096 + threadIdx.x * 4; base < n; base += gridDim.z * 4096) {
+        float v[16];                                   // four 16-byte (8-byte) loads in flight per lane
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * u + e] = (float)src[i + 1024 * u + e];
+            for (int e = 0; e < 4; ++e) v[4 * u + e] = (base + 1024 * u < n) ? (float)src[base + 1024 * u + e] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) bad |= (v[e] != v[e]);
-    }
-    for (; i < n; i += 1024) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = (float)src[i + e];
-            bad |= (v != v);
-        }
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) flags[2 * c.video + blockIdx.y] = 1;      // benign race: every writer stores 1
 }
 
-// one workgroup per (chunk, modality): valid rows from the packed input (fixed up if the video's flag is set), zeros behind them
-// (nrows = 256: whole chunks; nrows = 0: row-compressed, one zero row)
+// gridDim.z workgroups per (chunk, modality), 16-row groups dealt round-robin: valid rows from the packed input (fixed up if the
+// video's flag is set), zeros behind them (nrows = 256: whole chunks; nrows = 0: row-compressed, one zero row)
 template <typename T>
 __global__ __launch_bounds__(256) void iefvad_scatter_rows_kernel(const T* img, const T* ev, const RaggedChunk* chunks, const int* flags,
                                                                   float* out0, float* out1, __bf16* ob0, __bf16* ob1, int nrows) {
@@ -73,7 +68,7 @@ __global__ __launch_bounds__(256) void iefvad_scatter_rows_kernel(const T* img, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nr = nrows ? nrows : ragged_rows(c.valid);
     // four rows of the wave per trip: all their loads are issued before the first store (a 40-row chunk is 2-3 trips of pure latency)
-    for (int r0 = wave; r0 < nr; r0 += 16) {
+    for (int r0 = wave + 16 * blockIdx.z; r0 < nr; r0 += 16 * gridDim.z) {
         f32x4 v[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
