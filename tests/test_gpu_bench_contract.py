@@ -2,6 +2,7 @@
 block on SURVEY.md 8(d)'s algorithmic FLOPs, the CPU-oracle baseline, the side modes and the UCF-sized evaluation block.
 A reduced batch keeps this a ~30 s test; the numbers are not checked, the structure and the internal consistency are."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -52,3 +53,12 @@ def test_default_line_structure_and_consistency():
         c = e["vs_fp32_cpu_oracle_on_sample"]
         assert c["max_abs_score_diff"] <= 5e-3                               # bf16 gate on sigmoid(logit), tests/test_gpu_bf16.py
         assert c["abs_auc_diff"] <= 1e-4 and c["abs_ap_diff"] <= 1e-4
+        w = e["bf16_wire"]                                                   # the opt-in narrowed wire: beside the fp32-wire figure, same gates
+        assert w["snippets_per_s"] > 0 and w["max_abs_score_diff_vs_fp32_wire"] <= 5e-3
+        cw = w["vs_fp32_cpu_oracle_on_sample"]
+        assert cw["max_abs_score_diff"] <= 5e-3 and cw["abs_auc_diff"] <= 1e-4 and cw["abs_ap_diff"] <= 1e-4
+    t = d["train_step"]                                                      # both arithmetic modes of the training step
+    assert "compute=bf16x6" in t["workload"] and "compute=f32" in t["f32_mode"]["workload"]
+    for m in (t, t["f32_mode"]):
+        assert m["snippets_per_s"] > 0 and abs(m["snippets_per_s"] - 128 * 256 / (m["ms_per_step"] * 1e-3)) < 1e-6 * m["snippets_per_s"]
+        assert math.isfinite(m["loss_total"])
