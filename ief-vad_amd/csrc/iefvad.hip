@@ -17,6 +17,7 @@
 
 #include "attention_f32.h"
 #include "attention_bf16.h"
+#include "attention_pbf16.h"
 #include "attention_split.h"
 #include "common.h"
 #include "gather.h"
@@ -205,6 +206,10 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_heads_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HP_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_pbf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APB_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_pbf16_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APB_LDS_BYTES);
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, h->device);
@@ -887,7 +892,14 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 ab.chunks = enc_rows_mode ? rg->d_chunks : nullptr;
                 ab.head_major = ip_chain ? 1 : 0;
                 ab.nrows = rows;
-                if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_bf16_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
+                // from two items per CU on: the persistent kernel (attention_pbf16.h: one 8-wave workgroup per CU, K / V staged once for
+                // both query halves by LDS-DMA, the next item's K in flight under the current item); bit-identical to the one below
+                static const bool persist_att = [] { const char* v = getenv("IEFVAD_PERSIST_ATT"); return !(v && v[0] == '0'); }();
+                const int items = 2 * nb * IEF_H;
+                if (persist_att && items >= 2 * h->num_cus) {
+                    if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_pbf16_rows_kernel, dim3(h->num_cus), dim3(512), APB_LDS_BYTES, stream, ab);
+                    else hipLaunchKernelGGL(iefvad_attention_pbf16_kernel, dim3(h->num_cus), dim3(512), APB_LDS_BYTES, stream, ab);
+                } else if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_bf16_rows_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
                 else hipLaunchKernelGGL(iefvad_attention_bf16_kernel, dim3(IEF_H, 2, 2 * nb), dim3(256), 0, stream, ab);
             } else {
                 AttnArgs aa;
