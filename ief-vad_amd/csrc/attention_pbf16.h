@@ -51,6 +51,8 @@ __device__ __forceinline__ void attention_pbf16_body(const AttnBArgs& args, char
 
     struct Item { const bf16_t* qb; bf16_t* out; int last; };
     auto item_of = [&](int it) {
+        // head fastest: the eight 192-byte segments of an output row are written at about the same time and meet in L2 (chunk fastest,
+        // i.e. sequential 48 KB tiles per operand stream, measured 11 % slower)
         const int head = it & (IEF_H - 1), cm = it >> 3, chunk = cm % args.nchunks, mod = cm / args.nchunks;
         int row0 = chunk * IEF_T, last = IEF_T - 1;
         if constexpr (RG) {
