@@ -894,7 +894,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
                 ab.nrows = rows;
                 // from two items per CU on: the persistent kernel (attention_pbf16.h: one 8-wave workgroup per CU, K / V staged once for
                 // both query halves by LDS-DMA, the next item's K in flight under the current item); bit-identical to the one below
-                static const bool persist_att = [] { const char* v = getenv("IEFVAD_PERSIST_ATT"); return !(v && v[0] == '0'); }();
+                static const bool persist_att = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();      // one switch for the three persistent kernels
                 const int items = 2 * nb * IEF_H;
                 if (persist_att && items >= 2 * h->num_cus) {
                     if (enc_rows_mode) hipLaunchKernelGGL(iefvad_attention_pbf16_rows_kernel, dim3(h->num_cus), dim3(512), APB_LDS_BYTES, stream, ab);
