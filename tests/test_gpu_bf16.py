@@ -452,3 +452,46 @@ def test_row_block_encoder_and_heads_against_fp64_of_the_same_rounded_operands()
     # and such flips cascade through the two attention layers; the bf16-vs-fp32 gates are 4e-2 (768-d) and 1.5e-2 (logits)
     for k, (mx, mean) in worst.items():
         assert mx <= 6e-3 and mean <= 6e-4, (k, mx, mean)
+
+
+def test_persistent_kernels_equal_the_one_block_kernels(tmp_path):
+    """The three persistent kernels of the bf16 mode (out_proj + LayerNorm, heads + fusion, attention: one workgroup per CU walking
+    blocks / items, the next image by LDS-DMA) against the kernels they replace from two blocks per CU on -- IEFVAD_PERSIST=0, a
+    process-wide switch, hence two child processes.  B = 96 chunks (384 row blocks, 1,536 attention items: every persistent kernel
+    runs), dense and as a list of videos (the row-compressed attention variant): every output bit for bit, the row means of the
+    fusion weights to fp32 rounding (their summation order belongs to the kernel)."""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import argparse, sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import iefvad_amd\n"
+        "from iefvad_amd import synth\n"
+        "sd = synth.make_state_dict(14, 768, 2, 3)\n"
+        "a = argparse.Namespace(visual_layers=2, visual_head=8, num_refinement_steps=3, lambda_ref=0.5, noise_model='StudentT', nu=8)\n"
+        "m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, 2, 8, 10, 10, 'cuda', a, compute='bf16')\n"
+        "m.load_state_dict(sd); m = m.to('cuda:0').eval()\n"
+        "img, ev = synth.make_inputs(37, 96)\n"
+        "ti, te = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()\n"
+        "with torch.no_grad():\n"
+        "    out = m(ti, te, None, None, None)\n"
+        "    lens = [200 + (37 * i) %% 56 for i in range(96)]\n"
+        "    rows_i = torch.cat([ti[i, :n] for i, n in enumerate(lens)]); rows_e = torch.cat([te[i, :n] for i, n in enumerate(lens)])\n"
+        "    vid = m.forward_videos(rows_i, rows_e, lens)\n"
+        "np.savez(sys.argv[1], **{k: v.float().cpu().numpy() for k, v in out.items()}, **{'vid_' + k: v.cpu().numpy() for k, v in vid.items()})\n"
+    ) % os.path.dirname(H.GOLDEN.rstrip('/').rsplit('/', 1)[0])
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, IEFVAD_PERSIST=flag)
+        path = str(tmp_path / f"persist{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = np.load(path)
+    assert set(res["1"].files) == set(res["0"].files) and "vid_logits" in res["1"].files
+    for k in res["1"].files:
+        a, b = res["1"][k], res["0"][k]
+        if k.endswith("w_i_mean") or k.endswith("w_e_mean"):
+            assert np.allclose(a, b, rtol=0, atol=1e-6), k
+        else:
+            assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
