@@ -1,0 +1,122 @@
+// Weight gradients in the bf16x6 arithmetic: C[i, j] = sum_r A[r, i] B[r, j] with BOTH operands row-major over the contraction index
+// (dW = dY^T X of a Linear, /root/reference/model/imf_vad.py:115-150 under autograd; train.h `launch_dw`), fp32-accurate as
+// gemm_split.h: every fp32 operand element is the exact sum of three bf16 terms and a product is accumulated in fp32 from the six
+// largest bf16 MFMA products.
+//
+// Neither operand can be pre-split (both are activations of the step) and neither has the contraction index contiguous, so:
+//   * tiles are k-MAJOR fp32 images in LDS, [16 r][128 columns], filled by LDS-DMA (one 512-byte row segment per half wave) into a
+//     ring of FOUR buffers: a tile is 24 MFMAs per wave (0.4 us), so a tile requested one tile ahead would not have landed; requested
+//     three ahead and waited for by COUNT (`s_waitcnt vmcnt(8)`: the pieces of the two youngest tiles may still be in flight); the
+//     MFMA fragment of lane (i, h) -- eight consecutive r of ONE column -- is eight ds_read_b32 down a column: lanes i = 0..31 read
+//     consecutive dwords, and the 16-byte chunks of rows with (r >> 3) odd are XOR-swizzled by 8 (32 floats; on the per-lane SOURCE
+//     address) so that the two lane halves (r and r + 8) use different banks;
+//   * each wave splits the fragments it reads in registers (split8 of attention_split.h: 22 VALU per 8 elements and plane set):
+//     four fragments (two 32-column tiles of A, two of B) per 16-r tile feed 2 x 2 x 6 = 24 MFMAs.
+// 128 x 128 output tile, 4 waves (2 x 2) of 64 x 64, two workgroups per CU (64 KB of LDS: four buffers x (A + B) x 8 KB).  Split-K over
+// the rows in grid.z slices; each slice writes its partial tile, the caller reduces them in index order (deterministic).
+#pragma once
+#include "attention_split.h"
+
+struct TnArgs {
+    const float* A;      // [slices * R, lda]: dY
+    const float* B;      // [slices * R, ldb]: X
+    float* C;            // [slices][M][ldc] partial products
+    int M, N, R;         // M, N multiples of 128; R (rows per slice) a multiple of 16
+    int lda, ldb, ldc;
+    int tiles_n;         // N / 128
+};
+
+#define TN_BK 16
+#ifndef TN_NBUF
+#define TN_NBUF 3
+#endif
+#define TN_TILE_FLOATS (TN_BK * 128)                 // one operand tile: 8 KB
+#define TN_LDS_BYTES (TN_NBUF * 2 * TN_TILE_FLOATS * 4)      // [buffer b: A | B]
+
+__global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_tn_kernel(TnArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = (args.M / 128) * args.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = bid / tiles, tt = bid - z * tiles;
+    const int tm = tt / args.tiles_n, tn = tt - tm * args.tiles_n;
+    const int R = args.R, lda = args.lda, ldb = args.ldb;
+
+    // DMA: piece p (1 KB) of a tile = rows 2 p, 2 p + 1; lane L fills row 2 p + (L >> 5), 16-byte position L & 31, with the source
+    // chunk (L & 31) ^ 8 ((row >> 3) & 1).  Wave w sends pieces 2 w, 2 w + 1 of both operands: four requests per wave and tile.
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(args.A + (size_t)z * R * lda + tm * 128), 0, (R - 1) * lda * 4 + 512, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(args.B + (size_t)z * R * ldb + tn * 128), 0, (R - 1) * ldb * 4 + 512, 0x00020000);
+    int voa[2], vob[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = 2 * (2 * wave + p) + (lane >> 5), c = (lane & 31) ^ (((row >> 3) & 1) << 3);
+        voa[p] = row * lda * 4 + c * 16;
+        vob[p] = row * ldb * 4 + c * 16;
+    }
+    auto dma = [&](int kt, int buf) {
+        float* dA = tn_smem + buf * 2 * TN_TILE_FLOATS + (2 * wave) * 256;
+        float* dB = dA + TN_TILE_FLOATS;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dA + p * 256), 16, voa[p], kt * (TN_BK * lda * 4), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dB + p * 256), 16, vob[p], kt * (TN_BK * ldb * 4), 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment of 32-column tile t2 of an image: element j = img[(8 h + j) * 128 + 32 (t2 ^ h) + i]
+#define TN_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
+#define TN_SIX(x_, y_, c_) TN_MFMA(x_[2], y_[0], c_); TN_MFMA(x_[0], y_[2], c_); TN_MFMA(x_[1], y_[1], c_); TN_MFMA(x_[1], y_[0], c_); TN_MFMA(x_[0], y_[1], c_); TN_MFMA(x_[0], y_[0], c_)
+
+    const int nk = R / TN_BK;
+#pragma unroll
+    for (int b = 0; b < TN_NBUF - 1; ++b)
+        if (b < nk) dma(b, b);
+    // tile 0 has landed when at most the pieces of tiles 1 and 2 are in flight
+    if (nk >= TN_NBUF - 1 && TN_NBUF == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else if (nk >= 2) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + TN_NBUF - 1 < nk) dma(kt + TN_NBUF - 1, (kt + TN_NBUF - 1) % TN_NBUF);      // the buffer tile kt - 1 has left
+        const float* imgA = tn_smem + (kt % TN_NBUF) * 2 * TN_TILE_FLOATS;
+        const float* imgB = imgA + TN_TILE_FLOATS;
+        u32x4 pa[2][3], pb[2][3];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float* p = (f < 2 ? imgA : imgB) + 8 * h * 128 + 32 * (((f < 2 ? 2 * wm : 2 * wn) + (f & 1)) ^ h) + i;
+            const f32x4 lo = {p[0], p[128], p[256], p[384]}, hi = {p[512], p[640], p[768], p[896]};
+            split8<false, 3>(lo, hi, f < 2 ? pa[f & 1] : pb[f & 1], 1.0f);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { TN_SIX(pa[a], pb[b], acc[a][b]); }
+        // tile kt + 1 has landed when at most the pieces of the two tiles behind it (four requests each) are in flight
+        const int young = nk - kt - 2;
+        if (young >= 2 && TN_NBUF == 4) __builtin_amdgcn_s_waitcnt(0x0F78);          // vmcnt(8)
+        else if (young >= 1) __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        __syncthreads();                     // ... for every wave, and every wave has left this tile's images
+    }
+#undef TN_SIX
+#undef TN_MFMA
+    // partial tile out: accumulator column = lane & 31 (the B column), row = (r & 3) + 8 (r >> 2) + 4 h (the A column)
+    float* C = args.C + (size_t)z * args.M * args.ldc + (size_t)(tm * 128 + wm * 64) * args.ldc + tn * 128 + wn * 64;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(size_t)(32 * a + (r & 3) + 8 * (r >> 2) + 4 * h) * args.ldc + 32 * b + i] = acc[a][b][r];
+}

@@ -33,6 +33,7 @@
 #include "heads_pchain_bf16.h"
 #include "ragged.h"
 #include "loss.h"
+#include "gemm_split_tn.h"
 #include "backward.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -206,6 +207,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_heads_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HP_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_pbf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APB_LDS_BYTES);
     if (e == hipSuccess)
