@@ -24,6 +24,7 @@ struct TnArgs {
     int M, N, R;         // M, N multiples of 128; R (rows per slice) a multiple of 16
     int lda, ldb, ldc;
     int tiles_n;         // N / 128
+    float* colsum;       // nullable: [slices][M] partial column sums of A (the bias gradient of the same Linear: db = dY^T 1), fp32
 };
 
 #define TN_BK 16
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_t
 #define TN_SIX(x_, y_, c_) TN_MFMA(x_[2], y_[0], c_); TN_MFMA(x_[0], y_[2], c_); TN_MFMA(x_[1], y_[1], c_); TN_MFMA(x_[1], y_[0], c_); TN_MFMA(x_[0], y_[1], c_); TN_MFMA(x_[0], y_[0], c_)
 
     const int nk = R / TN_BK;
+    const bool do_cs = args.colsum != nullptr && tn == 0;
+    const int cs_c = t & 127, cs_h = t >> 7;
+    float cs = 0.f;
 #pragma unroll
     for (int b = 0; b < TN_NBUF - 1; ++b)
         if (b < nk) dma(b, b);
@@ -101,6 +105,11 @@ __global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_t
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) { TN_SIX(pa[a], pb[b], acc[a][b]); }
+        if (do_cs) {         // the column sums ride along in the workgroups of the first column block: 8 rows of one column per thread
+            const float* q = imgA + 8 * cs_h * 128 + (cs_c ^ (32 * cs_h));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs += q[j * 128];
+        }
         // tile kt + 1 has landed when at most the pieces of the two tiles behind it (four requests each) are in flight
         const int young = nk - kt - 2;
         if (young >= 2 && TN_NBUF == 4) __builtin_amdgcn_s_waitcnt(0x0F78);          // vmcnt(8)
@@ -110,6 +119,11 @@ __global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_t
     }
 #undef TN_SIX
 #undef TN_MFMA
+    if (do_cs) {             // (the loop ended with a barrier: the ring is dead)
+        tn_smem[t] = cs;
+        __syncthreads();
+        if (t < 128) args.colsum[(size_t)z * args.M + tm * 128 + t] = tn_smem[t] + tn_smem[t + 128];
+    }
     // partial tile out: accumulator column = lane & 31 (the B column), row = (r & 3) + 8 (r >> 2) + 4 h (the A column)
     float* C = args.C + (size_t)z * args.M * args.ldc + (size_t)(tm * 128 + wm * 64) * args.ldc + tn * 128 + wn * 64;
 #pragma unroll

@@ -179,7 +179,9 @@ static int launch_dx(iefvad_handle* h, const bf16_t* planes_t, const float* dY, 
 // dW[n_out, 768] = alpha * dY^T X over the rows, split-K with fixed-order reduction; dW may be null (frozen parameter).
 // `dW2` (nullable) receives rows [n_split, n_out) as a tensor of its own (the stacked mu | logvar heads).
 static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float* dW, float* dW2, int n_split, float alpha, int rows,
-                     float* part, size_t part_floats, hipStream_t stream, bool split_tn = false) {
+                     float* part, size_t part_floats, hipStream_t stream, bool split_tn = false, float* db = nullptr, float* db2 = nullptr,
+                     float* cpart = nullptr, size_t cpart_floats = 0, bool* db_done = nullptr) {
+    if (db_done) *db_done = false;
     if (!dW && !dW2) return 0;
     const int splits = splitk_splits(rows, n_out);
     const size_t per = (size_t)n_out * IEF_D;
@@ -190,6 +192,9 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
         TnArgs g;
         memset(&g, 0, sizeof(g));
         g.A = dY; g.B = X; g.C = part; g.M = n_out; g.N = IEF_D; g.R = ms; g.lda = ldy; g.ldb = IEF_D; g.ldc = IEF_D; g.tiles_n = IEF_D / 128;
+        // the bias gradient of the same Linear (column sums of dY) rides along in the first column block's workgroups
+        const bool with_db = (db || db2) && cpart && db_done && (size_t)splits * n_out <= cpart_floats;
+        g.colsum = with_db ? cpart : nullptr;
         hipLaunchKernelGGL(iefvad_gemm_split_tn_kernel, dim3((unsigned)((n_out / 128) * (IEF_D / 128) * splits)), dim3(256), TN_LDS_BYTES, stream, g);
         HIP_TRY(hipGetLastError());
         if (dW) {
@@ -200,6 +205,18 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
             const size_t n = (size_t)(n_out - n_split) * IEF_D;
             hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
                                per, splits, n, dW2, alpha);
+        }
+        if (with_db) {
+            if (db) {
+                const size_t n = n_split > 0 ? n_split : n_out;
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart, (size_t)n_out, splits, n, db, alpha);
+            }
+            if (db2) {
+                const size_t n = n_out - n_split;
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart + n_split, (size_t)n_out, splits,
+                                   n, db2, alpha);
+            }
+            *db_done = true;
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -473,12 +490,16 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
     // refinement steps, last to first (imf_vad.py:146-149): z_{k+1} = z_k - lambda (W2 relu(W1 z_k + b1) + b2); g = d z_{k+1}
     for (int k = K - 1; k >= 0; --k) {
         const float nl = -c.lambda_ref;
-        if (int rc = launch_dw(g, IEF_D, IEF_D, ws + t.hid[k], dw->ref_w2[k], nullptr, 0, nl, rows, part, t.part_floats, stream, tn)) return rc;
-        if (int rc = launch_db(g, IEF_D, IEF_D, dw->ref_b2[k], nullptr, 0, nl, rows, cpart, stream)) return rc;
+        { bool db_done = false;
+            if (int rc = launch_dw(g, IEF_D, IEF_D, ws + t.hid[k], dw->ref_w2[k], nullptr, 0, nl, rows, part, t.part_floats, stream, tn, dw->ref_b2[k], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (!db_done)
+                if (int rc = launch_db(g, IEF_D, IEF_D, dw->ref_b2[k], nullptr, 0, nl, rows, cpart, stream)) return rc; }
         // d a = (-lambda g W2) gated by h > 0  (ReLU backward on the saved activation)
         if (int rc = launch_dx(h, tp ? h->ref_w2st[k] : nullptr, g, IEF_D, h->ref_w2[k], IEF_D, IEF_D, da, nullptr, ws + t.hid[k], nl, rows, stream)) return rc;
-        if (int rc = launch_dw(da, IEF_D, IEF_D, ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn)) return rc;
-        if (int rc = launch_db(da, IEF_D, IEF_D, dw->ref_b1[k], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+        { bool db_done = false;
+            if (int rc = launch_dw(da, IEF_D, IEF_D, ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->ref_b1[k], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (!db_done)
+                if (int rc = launch_db(da, IEF_D, IEF_D, dw->ref_b1[k], nullptr, 0, 1.f, rows, cpart, stream)) return rc; }
         // d z_k = g + d a W1   (in place: every element of g is read by the thread that overwrites it)
         if (int rc = launch_dx(h, tp ? h->ref_w1st[k] : nullptr, da, IEF_D, h->ref_w1[k], IEF_D, IEF_D, g, g, nullptr, 1.f, rows, stream)) return rc;
     }
@@ -499,9 +520,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         const float* dhm = ws + t.dh[m];
         float* gx = ws + t.gx;
         // heads (imf_vad.py:125-128): mu.weight | logvar.weight are stacked [1536, 768] in the handle
-        if (int rc = launch_dw(dhm, 2 * IEF_D, 2 * IEF_D, ws + t.E[m], dw->mu_w[m], dw->logvar_w[m], IEF_D, 1.f, rows, part, t.part_floats, stream, tn))
-            return rc;
-        if (int rc = launch_db(dhm, 2 * IEF_D, 2 * IEF_D, dw->mu_b[m], dw->logvar_b[m], IEF_D, 1.f, rows, cpart, stream)) return rc;
+        { bool db_done = false;
+            if (int rc = launch_dw(dhm, 2 * IEF_D, 2 * IEF_D, ws + t.E[m], dw->mu_w[m], dw->logvar_w[m], IEF_D, 1.f, rows, part, t.part_floats, stream, tn, dw->mu_b[m], dw->logvar_b[m], cpart, t.cpart_floats, &db_done)) return rc;
+            if (!db_done)
+                if (int rc = launch_db(dhm, 2 * IEF_D, 2 * IEF_D, dw->mu_b[m], dw->logvar_b[m], IEF_D, 1.f, rows, cpart, stream)) return rc; }
         if (int rc = launch_dx(h, tp ? h->head_wst[m] : nullptr, dhm, 2 * IEF_D, h->head_w[m], 2 * IEF_D, IEF_D, gx, nullptr, nullptr, 1.f, rows, stream)) return rc;
         // whitening LayerNorm (imf_vad.py:117,123), then the layers last to first
         auto ln_bwd = [&](const float* x, const float* gamma, float* dgamma, float* dbeta) -> int {
@@ -528,8 +550,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             const float* P = ws + t.P[m][l];
             // Pd is P when neither a dropout probability nor a mask was in force in the forward
             const float* Pd = rec->drop[m][l] ? ws + t.Pd[m][l] : P;
-            if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn)) return rc;
-            if (int rc = launch_db(gx, IEF_D, IEF_D, dw->out_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+            { bool db_done = false;
+            if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->out_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (!db_done)
+                if (int rc = launch_db(gx, IEF_D, IEF_D, dw->out_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc; }
             if (int rc = launch_dx(h, tp ? h->out_wst[m][l] : nullptr, gx, IEF_D, h->out_w[m][l], IEF_D, IEF_D, datt, nullptr, nullptr, 1.f, rows, stream)) return rc;
             const long long sQ = (long long)IEF_T * 3 * IEF_D, sP1 = (long long)IEF_H * IEF_T * IEF_T, sP2 = (long long)IEF_T * IEF_T,
                             sA = (long long)IEF_T * IEF_D;
@@ -565,9 +589,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             a.a1 = sP1; a.a2 = sP2; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
             if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
             // in_proj (packed q | k | v, imf_vad.py:69-72)
-            if (int rc = launch_dw(dqkv, 3 * IEF_D, 3 * IEF_D, ws + t.x[m][l], dw->in_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn))
-                return rc;
-            if (int rc = launch_db(dqkv, 3 * IEF_D, 3 * IEF_D, dw->in_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc;
+            { bool db_done = false;
+            if (int rc = launch_dw(dqkv, 3 * IEF_D, 3 * IEF_D, ws + t.x[m][l], dw->in_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->in_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (!db_done)
+                if (int rc = launch_db(dqkv, 3 * IEF_D, 3 * IEF_D, dw->in_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc; }
             // d x_l = d s_l (residual) + d qkv W_in; the input features need no gradient
             if (l > 0)
                 if (int rc = launch_dx(h, tp ? h->in_wst[m][l] : nullptr, dqkv, 3 * IEF_D, h->in_w[m][l], 3 * IEF_D, IEF_D, gx, gx, nullptr, 1.f, rows, stream)) return rc;
