@@ -479,6 +479,9 @@ def train_step_one(dev, a, compute, chunks=128, steps=4):
                         f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute={compute}",
             "snippets_per_s": chunks * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_tflop_per_step": flops / 1e12,
             "achieved_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "peak_note": ("the fp32 MFMA peak is the yardstick of an fp32-accurate step; in bf16x6 every projection product (forward, dX, dW) runs "
+                          "as six bf16 MFMA products on the bf16 pipe, so the ratio can exceed 1") if compute == "bf16x6" else
+                         "every product on the fp32 MFMA instruction",
             "loss_total": float(terms["total"])}
 
 
