@@ -5,15 +5,17 @@
 //
 // Neither operand can be pre-split (both are activations of the step) and neither has the contraction index contiguous, so:
 //   * tiles are k-MAJOR fp32 images in LDS, [16 r][128 columns], filled by LDS-DMA (one 512-byte row segment per half wave) into a
-//     ring of FOUR buffers: a tile is 24 MFMAs per wave (0.4 us), so a tile requested one tile ahead would not have landed; requested
-//     three ahead and waited for by COUNT (`s_waitcnt vmcnt(8)`: the pieces of the two youngest tiles may still be in flight); the
+//     ring of THREE buffers: a tile is 24 MFMAs per wave (0.4 us), so a tile requested one tile ahead would not have landed; requested
+//     two ahead and waited for by COUNT (`s_waitcnt vmcnt(4)`: the four requests of the youngest tile may still be in flight; with
+//     -DTN_NBUF=4, three ahead and vmcnt(8): measured 1 % slower at its two workgroups per CU); the
 //     MFMA fragment of lane (i, h) -- eight consecutive r of ONE column -- is eight ds_read_b32 down a column: lanes i = 0..31 read
 //     consecutive dwords, and the 16-byte chunks of rows with (r >> 3) odd are XOR-swizzled by 8 (32 floats; on the per-lane SOURCE
 //     address) so that the two lane halves (r and r + 8) use different banks;
 //   * each wave splits the fragments it reads in registers (split8 of attention_split.h: 22 VALU per 8 elements and plane set):
 //     four fragments (two 32-column tiles of A, two of B) per 16-r tile feed 2 x 2 x 6 = 24 MFMAs.
-// 128 x 128 output tile, 4 waves (2 x 2) of 64 x 64, two workgroups per CU (64 KB of LDS: four buffers x (A + B) x 8 KB).  Split-K over
-// the rows in grid.z slices; each slice writes its partial tile, the caller reduces them in index order (deterministic).
+// 128 x 128 output tile, 4 waves (2 x 2) of 64 x 64, three workgroups per CU (48 KB of LDS: three buffers x (A + B) x 8 KB; 114
+// VGPRs).  Split-K over the rows in grid.z slices; each slice writes its partial tile, the caller reduces them in index order
+// (deterministic).  The workgroups of the first column block also sum the columns of their A tiles: the bias gradient.
 #pragma once
 #include "attention_split.h"
 
