@@ -98,7 +98,8 @@ def test_bf16x6_backward_on_the_split_kernel_at_a_batch_that_fills_its_grid():
     """B = 8 (2048 rows, 96 workgroups >= the 72 of the dispatch): in compute='bf16x6' the forward projections AND the backward's
     input-gradient products (dX = dY W, on three-plane splits of W^T; train.h `launch_dx`) run on the exact-split kernel.  Every
     parameter gradient against fp64 autograd through the oracle (itself pinned by the grad_*.npz fixtures at B = 3), the same
-    gate as the fixtures'; the f32 handle at the same size alongside, whose bits must differ (another arithmetic ran)."""
+    gate as the fixtures'; the f32 handle at the same size alongside, whose bits must differ (another arithmetic ran); weight gradients
+    on the split TN kernel (gemm_split_tn.h), bit-reproducible from run to run."""
     from oracle import iefvad_oracle as orc
     L, K, B = 2, 2, 8
     img, ev, _, _ = synth.make_train_batch(77, B)
@@ -107,11 +108,13 @@ def test_bf16x6_backward_on_the_split_kernel_at_a_batch_that_fills_its_grid():
         return o["logits"].sum() + 0.5 * (o["image_mu"] * o["event_logvar"]).sum() + 0.25 * (o["event_mu"] * o["image_logvar"]).sum()
 
     grads = {}
-    for compute in ("f32", "bf16x6"):
-        model, sd = make_model(5, L, K, "StudentT", 8, compute, 0.0)
+    for compute in ("f32", "bf16x6", "bf16x6 again"):
+        model, sd = make_model(5, L, K, "StudentT", 8, compute.split()[0], 0.0)
         model.train()
         scalar(model(torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda(), None, None, None)).backward()
         grads[compute] = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
+    for n in grads["bf16x6"]:          # split-K partials reduced in index order, no atomics: the split kernels reproduce their bits
+        assert torch.equal(grads["bf16x6"][n], grads["bf16x6 again"][n]), n
     sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     scalar(orc.forward(sd64, torch.from_numpy(img), torch.from_numpy(ev), orc.OracleConfig(num_layers=L, num_refinement_steps=K, nu=8),
                        dtype=torch.float64)).backward()
