@@ -117,7 +117,8 @@ def compute_ano_auc(classwise_gt, classwise_roc, repeat_factor=16, normal_keys=(
 
 
 def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np.ndarray, dataset: str,
-                    verbose: bool = True, normal_keys=('Normal',)) -> Dict[str, object]:
+                    verbose: bool = True, normal_keys=('Normal',), total_samples: bool = False,
+                    log: Optional[Callable] = None) -> Dict[str, object]:
     """Metric tail of test() (test.py:155-175): ROC-AUC / AP on the x16-repeated snippet scores, Ano-AUC
     over the abnormal classes, per-class AUC/AP.  `scores` are per-video vectors in test-list order; gt
     is indexed by the running snippet offset (test.py:129,153)."""
@@ -137,6 +138,8 @@ def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np
     if verbose:
         print("AUC1: {:.2f}  AP1: {:.2f}".format(roc * 100, ap * 100))
         print("Ano-AUC: {:.2f}".format(ano * 100))
+    if log is not None:      # ucf_test.py:158-162 / xd_test.py:155-159
+        log({'test/AP1': ap, 'test/ROC1': roc, 'test/Ano-AUC': ano})
     per_class = {}
     for c in keys:
         cls_pred = np.concatenate(cw_pred[c])   # raises on an empty class exactly as test.py:166-167 does
@@ -145,8 +148,13 @@ def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np
             continue
         c_roc = roc_auc_score(cls_gt, np.repeat(cls_pred, 16))
         c_ap = average_precision_score(cls_gt, np.repeat(cls_pred, 16))
-        if verbose:
+        if verbose and total_samples:      # ucf_test.py:173-174
+            print(c, 'ROC: {:.2f}  AP: {:.2f}'.format(c_roc * 100, c_ap * 100), end='\t')
+            print(f"Total Samples: {len(cls_gt)}")
+        elif verbose:
             print(c, 'ROC: {:.2f}  AP: {:.2f}'.format(c_roc * 100, c_ap * 100))
+        if log is not None:                # ucf_test.py:175-178 / xd_test.py:170-173
+            log({'classwise/ROC/' + c: c_roc, 'classwise/AP/' + c: c_ap})
         per_class[c] = (c_roc, c_ap)
     if verbose:
         print('-------------------------------------------------')
@@ -202,8 +210,8 @@ def _unpack_item(item, maxlen, dataset, label_map):
     img = item[0].squeeze(0)
     ev = item[1].squeeze(0)
     cls = item[2][0] if isinstance(item[2], (list, tuple)) else item[2]
-    if dataset == 'xd' and label_map is not None:
-        cls = label_map[cls.split('-')[0]]            # xd_test.py:68
+    if label_map is not None and (dataset == 'xd' or isinstance(label_map, _AlwaysRemap)):
+        cls = label_map[cls.split('-')[0]]            # xd_test.py:68 / test.py:80-81
     length = int(item[3])
     if length < maxlen:
         img = img.unsqueeze(0)
@@ -220,8 +228,8 @@ def _unpack_rows(item, maxlen, dataset, label_map):
     crosses the boundary in the ragged path: per modality the item's own [..., D] tensor, whose first `length` rows are the
     valid ones (no view is built: two tensor ops per video were a third of the loop's host time on short videos)."""
     cls = item[2][0] if isinstance(item[2], (list, tuple)) else item[2]
-    if dataset == 'xd' and label_map is not None:
-        cls = label_map[cls.split('-')[0]]            # xd_test.py:68
+    if label_map is not None and (dataset == 'xd' or isinstance(label_map, _AlwaysRemap)):
+        cls = label_map[cls.split('-')[0]]            # xd_test.py:68 / test.py:80-81
     length = int(item[3])
     img, ev = item[0], item[1]
     if not img.is_contiguous():
@@ -776,23 +784,66 @@ def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch
     return res
 
 
-def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,
-         batch_chunks: int = 0, normal_keys=('Normal',), lanes: int = 1):
-    """Same positional signature and return value as the reference's `test()` (test.py:46-56;
-    ucf_test.py:16-26; xd_test.py passes `label_map` as an extra positional, :23).
-    Returns (ROC1, AP1) -- or (ROC1, AP1, attn_weights, labels) when attn=True, where attn_weights is the
-    empty list the reference also returns (it never fills it, test.py:73,209-210)."""
+def _run_test(args, model, test_loader, maxlen, gt, device, label_map, attn, vis, normal_keys, total_samples, log,
+              batch_chunks, lanes):
+    """The body the three `test()` functions of the reference share (test.py:57-212): model.to / eval, the per-video
+    loop, the metric tail, the prints.  What differs between the files is passed in: the Ano-AUC filter, the
+    "Total Samples" suffix of ucf_test.py:173-174 and the `wandb.log` calls (ucf_test.py:158-162,175-178 /
+    xd_test.py:155-159,170-173), which go to `log` when the caller supplies one (wandb itself is out of scope)."""
     model.to(device)
     model.eval()
     scores, classes, wi, we = score_loader(model, test_loader, maxlen, device, args.dataset, label_map, batch_chunks,
                                            lanes=lanes)
-    res = evaluate_scores(scores, classes, gt, args.dataset, verbose=True, normal_keys=normal_keys)
-    test.last_result = dict(res, scores=scores, classes=classes, w_i_mean=wi, w_e_mean=we)
+    res = evaluate_scores(scores, classes, gt, args.dataset, verbose=True, normal_keys=normal_keys,
+                          total_samples=total_samples, log=log)
+    last = dict(res, scores=scores, classes=classes, w_i_mean=wi, w_e_mean=we)
     if vis:
         print("[iefvad_amd] vis=True: plotting (test.py:177-207) is outside the hot-path scope; skipped")
-    if attn:
-        return res["roc"], res["ap"], [], classes
-    return res["roc"], res["ap"]
+    if attn:     # the reference returns the empty list it never fills (test.py:73,209-210)
+        return (res["roc"], res["ap"], [], classes), last
+    return (res["roc"], res["ap"]), last
+
+
+def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,
+         batch_chunks: int = 0, normal_keys=('Normal',), lanes: int = 1):
+    """Counterpart of ROOT `test.py`'s `test()` (test.py:46-56; call site test.py:380-390): same positional order
+    (..., device, attn, vis), Ano-AUC over every class but 'Normal' (test.py:336).  `label_map` is keyword-only in
+    spirit: root test.py reads a global for the xd remap (test.py:81).  Returns (ROC1, AP1), or
+    (ROC1, AP1, attn_weights, labels) when attn=True.  For `train/ucf_test.py` and `train/xd_test.py` -- whose
+    positional orders differ from this one and from each other -- use `ucf_test` / `xd_test` below."""
+    ret, test.last_result = _run_test(args, model, test_loader, maxlen, gt, device, label_map, attn, vis, normal_keys,
+                                      False, None, batch_chunks, lanes)
+    return ret
+
+
+def ucf_test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, *, log=None,
+             batch_chunks: int = 0, lanes: int = 1):
+    """Drop-in for `train/ucf_test.py`'s `test` (ucf_test.py:16-26; call site ucf_train.py:130-139): positional order
+    (..., device, attn, vis); Ano-AUC excludes BOTH 'Normal' and 'normal' (ucf_test.py:340); the per-class lines carry
+    "Total Samples" (ucf_test.py:173-174).  `log` (e.g. `wandb.log`) receives the dicts the reference logs."""
+    ret, ucf_test.last_result = _run_test(args, model, test_loader, maxlen, gt, device, None, attn, vis,
+                                          ('Normal', 'normal'), True, log, batch_chunks, lanes)
+    test.last_result = ucf_test.last_result
+    return ret
+
+
+def xd_test(args, model, test_loader, maxlen, prompt_text, gt, device, label_map, vis=False, attn=False, *, log=None,
+            batch_chunks: int = 0, lanes: int = 1):
+    """Drop-in for `train/xd_test.py`'s `test` (xd_test.py:15-26; call site xd_train.py:102-112): `label_map` is the
+    8th positional, then (vis, attn) -- the reverse of ucf_test's order; every video's class is
+    `label_map[cls.split('-')[0]]` whatever args.dataset says (xd_test.py:68, unconditional); Ano-AUC excludes
+    'normal' only (xd_test.py:334)."""
+    if label_map is None:
+        raise TypeError("xd_test: label_map is required (xd_test.py:68 indexes it for every video)")
+    ret, xd_test.last_result = _run_test(args, model, test_loader, maxlen, gt, device, _AlwaysRemap(label_map), attn, vis,
+                                         ('normal',), False, log, batch_chunks, lanes)
+    test.last_result = xd_test.last_result
+    return ret
+
+
+class _AlwaysRemap(dict):
+    """Marks a label map whose remap applies for every dataset name (xd_test.py:68) -- `harness.test` applies it for
+    args.dataset == 'xd' only, as root test.py:80-81 does."""
 
 
 # ------------------------------------------------------------------------------------------------

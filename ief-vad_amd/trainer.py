@@ -5,7 +5,7 @@
 One step = what ucf_train.py:43-106 does: `model.train()`, the conditional `nan_to_num` of the batch (:50-53), the forward
 (`iefvad_train_forward`), CLAS2 + cosine / norm regulariser + Gaussian / Student-t KL (`iefvad_loss_forward`), `zero_grad`,
 `loss.backward()` (`iefvad_loss_backward` then `iefvad_train_backward`), `optimizer.step()` (`iefvad_adamw_step`).  Around it the
-loops keep the reference's bookkeeping: evaluation every `print_steps` samples through `harness.test`, the best checkpoint
+loops keep the reference's bookkeeping: evaluation every `print_steps` samples through `harness.ucf_test` / `harness.xd_test`, the best checkpoint
 (`{'epoch', 'model_state_dict', 'optimizer_state_dict', 'ap'}`, :141-149), `scheduler.step()` and the reload of the best
 checkpoint at every epoch end (:151-153), the final rewrite as a bare state_dict (:155-156).  Logging goes to a callback instead
 of wandb.  No torch op computes a loss or a gradient here.
@@ -115,8 +115,8 @@ def train_paired(args, model, normal_loader, abnormal_loader, test_loader, label
             step = i * normal_loader.batch_size * 2                                    # ucf_train.py:42,106
             if step % args.print_steps == 0 and step != 0:
                 rec = {f'train/loss_{k}' if k != 'total' else 'train/loss': float(v) for k, v in terms.items()}
-                auc, ap = harness.test(args, model, test_loader, args.visual_length, prompt_text, gt, device, vis=False,
-                                       batch_chunks=eval_batch_chunks)
+                auc, ap = harness.ucf_test(args, model, test_loader, args.visual_length, prompt_text, gt, device,   # ucf_train.py:130-139
+                                           vis=False, batch_chunks=eval_batch_chunks)
                 rec.update(epoch=e, step=step, auc=auc, ap=ap)
                 if log:
                     log(rec)
@@ -148,8 +148,8 @@ def train_single(args, model, train_loader, test_loader, label_map, device, gt: 
             step = i * train_loader.batch_size
             if step % args.print_steps == 0 and step != 0:
                 rec = {f'train/loss_{k}' if k != 'total' else 'train/loss': float(v) for k, v in terms.items()}
-                auc, ap = harness.test(args, model, test_loader, args.visual_length, prompt_text, gt, device, vis=False,
-                                       label_map=label_map, batch_chunks=eval_batch_chunks, normal_keys=('normal',))
+                auc, ap = harness.xd_test(args, model, test_loader, args.visual_length, prompt_text, gt, device, label_map,   # xd_train.py:102-112
+                                          vis=False, batch_chunks=eval_batch_chunks)
                 rec.update(epoch=e, step=step, auc=auc, ap=ap)
                 if log:
                     log(rec)

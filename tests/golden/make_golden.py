@@ -178,6 +178,75 @@ def gen_harness_case():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "ROC", roc, "AP", ap, "ano", captured["ano"])
 
 
+XD_LENGTHS = [60, 256, 130, 300, 45, 90, 513, 20, 77]
+XD_LABELS = ["A", "B1-0-0", "B2-0-0", "B4-0-0", "B5-0-0", "B6-0-0", "G-0-0", "B1-B2-0", "A"]
+
+
+def gen_harness_xd_case():
+    """The XD-Violence form of the evaluation loop: labels are codes ("B1-0-0", "B1-B2-0", "A") remapped through
+    configs/xd_label_map.json by their first field (/root/reference/test.py:80-81, train/xd_test.py:68), seven class keys
+    (test.py:29-33).  train/xd_test.py cannot be imported here (wandb), so the capture runs root `test.test()` with
+    args.dataset = 'xd' and the module global `label_map` set as test.py's `__main__` block sets it (test.py:419-422);
+    the loop body is xd_test.py's line for line.  Per-video scores, ROC1, AP1 pin `harness.xd_test`; its
+    Ano-AUC filter ('normal', xd_test.py:334) differs from test.py:336's and is recomputed by the test from the
+    captured scores with sklearn."""
+    import json
+    sys.path.insert(0, REF)
+    seed = 5
+    tmp = tempfile.mkdtemp(prefix="iefvad_xd_")
+    os.makedirs(os.path.join(tmp, "feat", "rgb"))
+    os.makedirs(os.path.join(tmp, "feat", "event_thr_10"))
+    rows = []
+    for i, (n, c) in enumerate(zip(XD_LENGTHS, XD_LABELS)):
+        img, ev = synth.make_video(seed, i, n)
+        p = os.path.join(tmp, "feat", "rgb", f"v{i:03d}_label_{c}__5.npy")
+        np.save(p, img)
+        np.save(p.replace("rgb", "event_thr_10"), ev)
+        rows.append((p, c))
+    csv = os.path.join(tmp, "test.csv")
+    with open(csv, "w") as f:
+        f.write("path,label\n" + "".join(f"{p},{c}\n" for p, c in rows))
+    gt = synth.make_gt(seed, int(sum(XD_LENGTHS)))
+    with open(os.path.join(REF, "configs", "xd_label_map.json")) as f:
+        label_map = json.load(f)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        import test as ref_test
+        from data.dataset import XD_Dataset
+        from torch.utils.data import DataLoader
+        model = build_reference(12, K=3)
+        logits = []
+
+        class Recorder(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, *a, **k):
+                o = self.inner(*a, **k)
+                logits.append(o["logits"].detach().clone())
+                return o
+
+        ref_test.label_map = label_map
+        loader = DataLoader(XD_Dataset(256, csv, True, label_map), batch_size=1, shuffle=False)
+        args = argparse.Namespace(exp_name="golden", dataset="xd")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            roc, ap = ref_test.test(args, Recorder(model), loader, 256, None, gt, "cpu", attn=False, vis=False)
+        print(buf.getvalue())
+    finally:
+        os.chdir(cwd)
+    probs = [torch.sigmoid(lg.reshape(-1)[:n]).numpy() for lg, n in zip(logits, XD_LENGTHS)]
+    path = os.path.join(HERE, "harness_xd.npz")
+    np.savez_compressed(path, scores=np.concatenate(probs), lengths=np.array(XD_LENGTHS), labels=np.array(XD_LABELS),
+                        classes=np.array([label_map[c.split('-')[0]] for c in XD_LABELS]),
+                        map_keys=np.array(list(label_map.keys())), map_values=np.array(list(label_map.values())),
+                        roc=np.array(roc), ap=np.array(ap), seed=np.array(seed), wseed=np.array(12), K=np.array(3),
+                        stdout=np.array(buf.getvalue()))
+    print("wrote", path, os.path.getsize(path), "B", "ROC", roc, "AP", ap)
+
+
 SWEEP_LENGTHS = [40, 300, 17, 256, 90, 520]
 
 
@@ -486,6 +555,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b48":
         gen_forward_cases([BIG_CASE], BIG_CASE_CHUNKS)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "xd":
+        gen_harness_xd_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gen_sweep_case()
         sys.exit(0)
@@ -493,6 +565,7 @@ if __name__ == "__main__":
     gen_forward_cases()
     gen_forward_cases([BIG_CASE], BIG_CASE_CHUNKS)
     gen_harness_case()
+    gen_harness_xd_case()
     gen_init_checksums()
     gen_sweep_case()
     gen_config5_gt()

@@ -98,3 +98,27 @@ def write_config1_set(tmp, golden_dir=GOLDEN):
     sd = synth.make_state_dict(int(g["wseed"]))
     args = argparse.Namespace(dataset="ucfcrime", visual_length=256, test_list=str(csv), exp_name="t")
     return g, args, gt, sd
+
+
+def write_xd_set(tmp, golden_dir=GOLDEN):
+    """The XD-shaped .npy set of tests/golden/make_golden.py::gen_harness_xd_case (label CODES in the list, remapped by the
+    loop).  Returns (golden capture, args namespace, gt, state_dict, label_map)."""
+    import argparse
+    g = np.load(os.path.join(golden_dir, "harness_xd.npz"))
+    seed = int(g["seed"])
+    (tmp / "feat" / "rgb").mkdir(parents=True, exist_ok=True)
+    (tmp / "feat" / "event_thr_10").mkdir(parents=True, exist_ok=True)
+    rows = []
+    for i, (n, c) in enumerate(zip(g["lengths"], g["labels"])):
+        img, ev = synth.make_video(seed, i, int(n))
+        p = str(tmp / "feat" / "rgb" / f"v{i:03d}_label_{c}__5.npy")
+        np.save(p, img)
+        np.save(p.replace("rgb", "event_thr_10"), ev)
+        rows.append((p, str(c)))
+    csv = tmp / "test.csv"
+    csv.write_text("path,label\n" + "".join(f"{p},{c}\n" for p, c in rows))
+    gt = synth.make_gt(seed, int(g["lengths"].sum()))
+    sd = synth.make_state_dict(int(g["wseed"]), 768, 2, int(g["K"]))
+    args = argparse.Namespace(dataset="xd", visual_length=256, test_list=str(csv), exp_name="t")
+    label_map = {str(k): str(v) for k, v in zip(g["map_keys"], g["map_values"])}
+    return g, args, gt, sd, label_map

@@ -173,3 +173,24 @@ def test_refresh_weights_after_a_data_write():
         model.temporal.classifier.bias.add_(1.0)               # a versioned in-place op is noticed by itself
         c = model(img, ev)["logits"].clone()
     assert torch.allclose(b, a + 1.0, atol=1e-6) and torch.allclose(c, a + 2.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("batch_chunks", [0, 8])
+def test_xd_test_entry_reproduces_the_reference_capture_through_the_hip_path(tmp_path, golden_dir, capsys, batch_chunks):
+    """`harness.xd_test` called positionally as /root/reference/train/xd_train.py:102-112 calls `test` (label_map 8th), HIP model:
+    the reference's own run on the XD-shaped set (label codes remapped by their first field, seven class keys)."""
+    g, args, gt, sd, label_map = H.write_xd_set(tmp_path, golden_dir)
+    a = argparse.Namespace(visual_layers=2, visual_head=8, num_refinement_steps=int(g["K"]), lambda_ref=0.5, noise_model="StudentT", nu=8)
+    model = iefvad_amd.MMFMIL(7, 768, 256, 768, 8, 2, 8, 10, 10, "cuda", a, outputs="scores")
+    model.load_state_dict(sd)
+    ret = harness.xd_test(args, model, harness.get_test_loader(args), 256, None, gt, "cuda:0", label_map, vis=False,
+                          batch_chunks=batch_chunks)
+    assert len(ret) == 2
+    res = harness.xd_test.last_result
+    assert res["classes"] == [str(c) for c in g["classes"]]
+    assert np.abs(np.concatenate(res["scores"]) - g["scores"]).max() <= H.TOL_SIGMOID
+    assert abs(ret[0] - float(g["roc"])) < 1e-4 and abs(ret[1] - float(g["ap"])) < 1e-4
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    ref_lines = [ln for ln in str(g["stdout"]).splitlines() if ln.strip()]
+    assert out[0] == ref_lines[0]
+    assert [ln for ln in out if " ROC:" in ln] == [ln for ln in ref_lines if " ROC:" in ln]

@@ -196,3 +196,92 @@ def test_has_nan_matches_isnan_any():
     h[0, 0, 0] = float("nan")
     assert harness._has_nan(h)
     assert not harness._has_nan(torch.zeros(3, dtype=torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# the three test() entries against the reference's three call sites
+# ------------------------------------------------------------------------------------------------
+def test_three_test_entries_bind_the_reference_call_sites_verbatim():
+    """The reference calls its three `test()` functions with three different argument lists.  Each call is bound here,
+    argument for argument as the reference writes it, against the entry that replaces it; `label_map`, `vis`, `attn`
+    must land where the reference's own signature puts them."""
+    import inspect
+    A, M, L, T, P, G, D = (object() for _ in range(7))
+    LM = {"A": "normal"}
+    # /root/reference/test.py:380-390:  test(args, model, test_loader, args.visual_length, None, gt, device, attn=False, vis=True)
+    b = inspect.signature(harness.test).bind(A, M, L, T, None, G, D, attn=False, vis=True)
+    assert b.arguments["device"] is D and b.arguments["attn"] is False and b.arguments["vis"] is True
+    # /root/reference/train/ucf_train.py:130-139:  test(args, model, test_loader, args.visual_length, prompt_text, gt, device, vis=...)
+    b = inspect.signature(harness.ucf_test).bind(A, M, L, T, P, G, D, vis=True)
+    assert b.arguments["prompt_text"] is P and b.arguments["device"] is D and b.arguments["vis"] is True
+    assert "attn" not in b.arguments                                    # default False, ucf_test.py:24
+    # /root/reference/train/xd_train.py:102-112:  test(args, model, test_loader, args.visual_length, prompt_text, gt, device, label_map, vis=...)
+    b = inspect.signature(harness.xd_test).bind(A, M, L, T, P, G, D, LM, vis=False)
+    assert b.arguments["label_map"] is LM and b.arguments["vis"] is False and "attn" not in b.arguments
+    # positional ORDER of the tails, as the reference declares them (ucf_test.py:24-25: attn, vis; xd_test.py:23-25: label_map, vis, attn)
+    names = lambda f: [p.name for p in inspect.signature(f).parameters.values()
+                       if p.kind is inspect.Parameter.POSITIONAL_OR_KEYWORD]
+    head = ["args", "model", "test_loader", "maxlen", "prompt_text", "gt", "device"]
+    assert names(harness.ucf_test) == head + ["attn", "vis"]
+    assert names(harness.xd_test) == head + ["label_map", "vis", "attn"]
+    assert names(harness.test)[:9] == head + ["attn", "vis"]
+    # xd_test.py:68 indexes label_map for every video: a missing map is an error at the call, not a silent skip
+    with pytest.raises(TypeError):
+        inspect.signature(harness.xd_test).bind(A, M, L, T, P, G, D)
+
+
+@pytest.fixture(scope="module")
+def xdset(tmp_path_factory, golden_dir):
+    return H.write_xd_set(tmp_path_factory.mktemp("xd"), golden_dir)
+
+
+def test_xd_test_entry_reproduces_the_reference_capture(xdset, capsys):
+    """`harness.xd_test`, called as xd_train.py:102-112 calls it, against the reference's own run on the XD-shaped set
+    (root test.test with dataset 'xd' -- the same loop; tests/golden/make_golden.py::gen_harness_xd_case)."""
+    from sklearn.metrics import roc_auc_score
+    g, args, gt, sd, label_map = xdset
+    model = orc.OracleMMFMIL(sd, orc.OracleConfig(num_refinement_steps=int(g["K"])))
+    logged = []
+    ret = harness.xd_test(args, model, harness.get_test_loader(args), 256, ["p"], gt, "cpu", label_map, vis=False, log=logged.append)
+    assert isinstance(ret, tuple) and len(ret) == 2                    # `AUC, AP = test(...)`, xd_train.py:102
+    roc, ap = ret
+    res = harness.xd_test.last_result
+    assert res["classes"] == [str(c) for c in g["classes"]]            # remapped by the first label field, xd_test.py:68
+    scores = np.concatenate(res["scores"])
+    assert np.abs(scores - g["scores"]).max() < 2e-6
+    assert abs(roc - float(g["roc"])) < 1e-4 and abs(ap - float(g["ap"])) < 1e-4
+    # Ano-AUC of xd_test.py:328-346: every class but 'normal', straight from the CAPTURED scores with sklearn
+    offs = np.concatenate([[0], np.cumsum(g["lengths"])])
+    keep = [i for i, c in enumerate(g["classes"]) if str(c) != "normal"]
+    want = roc_auc_score(np.concatenate([gt[16 * offs[i]:16 * offs[i + 1]] for i in keep]),
+                         np.repeat(np.concatenate([g["scores"][offs[i]:offs[i + 1]] for i in keep]), 16))
+    assert abs(res["ano_auc"] - want) < 1e-4
+    out = capsys.readouterr().out.splitlines()
+    ref_lines = [l for l in str(g["stdout"]).splitlines() if l.strip()]
+    assert out[0] == ref_lines[0]                                       # "AUC1: ..  AP1: .."
+    assert [l for l in out if "ROC:" in l] == [l for l in ref_lines if "ROC:" in l]      # no "Total Samples" in xd_test.py:168
+    assert set(logged[0]) == {"test/AP1", "test/ROC1", "test/Ano-AUC"} and len(logged) == 1 + 7
+    # attn=True as a keyword (xd_test.py:25): the 4-tuple with the list the reference never fills
+    r4 = harness.xd_test(args, model, harness.get_test_loader(args), 256, None, gt, "cpu", label_map, False, True)
+    assert len(r4) == 4 and r4[2] == [] and r4[3] == res["classes"]
+
+
+def test_ucf_test_entry_filter_and_total_samples(config1, capsys):
+    """`harness.ucf_test` as ucf_train.py:130-139 calls it: same scores / AUC / AP as the capture; the per-class lines end in
+    "Total Samples: n" (ucf_test.py:173-174); Ano-AUC leaves out 'Normal' AND 'normal' (ucf_test.py:340)."""
+    g, args, gt, sd = config1
+    model = orc.OracleMMFMIL(sd, orc.OracleConfig())
+    auc, ap = harness.ucf_test(args, model, harness.get_test_loader(args), 256, None, gt, "cpu", vis=False)
+    assert abs(auc - float(g["roc"])) < 1e-4 and abs(ap - float(g["ap"])) < 1e-4
+    assert abs(harness.ucf_test.last_result["ano_auc"] - float(g["ano_auc"])) < 1e-4   # no 'normal' key in the UCF set: same value
+    out = capsys.readouterr().out
+    cls_lines = [l for l in out.splitlines() if "ROC:" in l]
+    assert len(cls_lines) == 14 and all("\tTotal Samples: " in l for l in cls_lines)
+    # the three filters on one synthetic class table (test.py:336 / ucf_test.py:340 / xd_test.py:334)
+    one, zero = np.ones(16), np.zeros(16)
+    cw_gt = {"Normal": [np.concatenate([one, zero])], "normal": [np.concatenate([zero, one])], "x": [np.concatenate([one, zero])]}
+    cw_pr = {"Normal": [np.array([0.9, 0.2])], "normal": [np.array([0.8, 0.3])], "x": [np.array([0.6, 0.5])]}
+    assert harness.compute_ano_auc(cw_gt, cw_pr, normal_keys=("Normal", "normal")) == 1.0      # 'x' alone: perfectly ranked
+    a_root = harness.compute_ano_auc(cw_gt, cw_pr, normal_keys=("Normal",))       # 'normal' (inverted) + 'x'
+    a_xd = harness.compute_ano_auc(cw_gt, cw_pr, normal_keys=("normal",))         # 'Normal' + 'x'
+    assert a_xd == 1.0 and a_root < 1.0
