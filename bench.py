@@ -440,7 +440,7 @@ def dataset_eval(tag, parts, wseed, K, compute, dev, a, batch_chunks=128, lanes=
 
 def train_step_block(dev, a, chunks=128, steps=4):
     """Both arithmetic modes of the training path: the headline's (bf16x6: forward projections and the backward's input-gradient
-    products on the exact-split kernel, weight gradients on the fp32 MFMA kernel) first, fp32 MFMA throughout beside it."""
+    products on the exact-split NT kernel, weight gradients on the split TN kernel, csrc/gemm_split_tn.h) first, fp32 MFMA throughout beside it."""
     out = train_step_one(dev, a, "bf16x6", chunks, steps)
     out["f32_mode"] = train_step_one(dev, a, "f32", chunks, steps)
     return out

@@ -453,24 +453,12 @@ __global__ __launch_bounds__(256) void iefvad_layernorm_bwd_kernel(LnBwdArgs a) 
         if (row >= a.rows) break;
         const size_t base = (size_t)row * IEF_D + 4 * lane;
         f32x4 v[3], d[3];
-        float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             v[j] = *(const f32x4*)(a.x + base + 256 * j);
             d[j] = *(const f32x4*)(a.dy + base + 256 * j);
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         }
-        const float mean = wave_sum(s) * (1.0f / IEF_D);            // ln_row's operations (rowops.h)
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float c = v[j][e] - mean;
-                v[j][e] = c;
-                ss += c * c;
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / IEF_D) + a.eps);
+        const float rstd = ln_center_rstd(v, a.eps);                // the forward's own statistics, bit for bit (rowops.h)
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j)

@@ -16,130 +16,7 @@
 // Staging slots, device input slots and the forward's workspace belong to the handle and are reused across calls (pinning memory
 // costs milliseconds per 100 MB).  A slot is rewritten only after the event behind its last use has completed.
 #pragma once
-#include <algorithm>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
-
-// fp32 -> bf16 (round to nearest even, NaN -> quiet NaN with its sign: what the device's v_cvt_pk_bf16_f32 gives) with non-temporal
-// stores: the staging form of wire_dtype = BF16 (include/iefvad.h).  n_src bytes of fp32 in, n_src / 2 bytes out; the caller keeps
-// ranges at multiples of 64 source bytes.
-#define IEF_CONVERT_BODY                                                                                                     \
-    typedef unsigned u8v __attribute__((vector_size(32)));                                                                   \
-    typedef unsigned u8vu __attribute__((vector_size(32), aligned(1)));                                                      \
-    typedef int i8v __attribute__((vector_size(32)));                                                                        \
-    typedef unsigned short h8v __attribute__((vector_size(16)));                                                             \
-    typedef unsigned short h16v __attribute__((vector_size(32)));                                                            \
-    size_t i = 0;                                                                                                            \
-    if (((uintptr_t)d & 31) == 0) {                                                                                          \
-        for (; i + 64 <= n_src; i += 64) {                                                                                   \
-            h8v half[2];                                                                                                     \
-            for (int q = 0; q < 2; ++q) {                                                                                    \
-                const u8v u = *(const u8vu*)(s + i + 32 * q);                                                                \
-                const u8v r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                                                        \
-                const i8v isnan = (i8v)((u & 0x7FFFFFFFu) > 0x7F800000u);                                                    \
-                const u8v o = ((u8v)isnan & ((u >> 16) | 0x40u)) | (~(u8v)isnan & r);                                        \
-                half[q] = __builtin_convertvector(o, h8v);                                                                   \
-            }                                                                                                                \
-            const h16v both = __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
-            __builtin_nontemporal_store(both, (h16v*)(d + i / 2));                                                           \
-        }                                                                                                                    \
-    }                                                                                                                        \
-    for (; i + 4 <= n_src; i += 4) {                                                                                         \
-        unsigned u;                                                                                                          \
-        memcpy(&u, s + i, 4);                                                                                                \
-        const unsigned short o = ((u & 0x7FFFFFFFu) > 0x7F800000u) ? (unsigned short)((u >> 16) | 0x40u)                      \
-                                                                   : (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); \
-        memcpy(d + i / 2, &o, 2);                                                                                            \
-    }
-__attribute__((target("avx2"))) static void stream_convert_bf16_avx2(char* d, const char* s, size_t n_src) { IEF_CONVERT_BODY }
-static void stream_convert_bf16_base(char* d, const char* s, size_t n_src) { IEF_CONVERT_BODY }
-#undef IEF_CONVERT_BODY
-static void stream_convert_bf16(char* d, const char* s, size_t n_src) {
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) stream_convert_bf16_avx2(d, s, n_src);
-    else stream_convert_bf16_base(d, s, n_src);
-}
-
-// A few persistent copy threads: a job is one byte stream (the concatenation of `count` pieces) cut into equal byte ranges, one per
-// thread -- a range may start and end inside a piece, so short and long videos balance.  Threads sleep between jobs.
-struct GatherPool {
-    std::vector<std::thread> threads;
-    std::mutex mu;
-    std::condition_variable cv_go, cv_done;
-    unsigned long long generation = 0;
-    int pending = 0;
-    bool stop = false;
-    // the job
-    char* dst = nullptr;
-    const void* const* srcs = nullptr;
-    const size_t* offs = nullptr;        // count + 1 prefix sums of the piece sizes (SOURCE bytes)
-    int64_t count = 0;
-    bool to_bf16 = false;                // the pieces are fp32, the destination takes them as bf16 (half the bytes)
-
-    void work(int t, int nt) {
-        const size_t total = offs[count];
-        const size_t step = (total / nt) & ~(size_t)63;      // ranges start at multiples of 64 source bytes (16 fp32 -> one 32-byte store)
-        const size_t lo = step * t, hi = (t == nt - 1) ? total : step * (t + 1);
-        if (hi <= lo) return;
-        int64_t i = (int64_t)(std::upper_bound(offs, offs + count + 1, lo) - offs) - 1;      // piece that holds byte lo
-        size_t pos = lo;
-        while (pos < hi) {
-            const size_t end = offs[i + 1] < hi ? offs[i + 1] : hi;
-            if (end > pos) {
-                if (to_bf16) stream_convert_bf16(dst + pos / 2, (const char*)srcs[i] + (pos - offs[i]), end - pos);
-                else stream_copy(dst + pos, (const char*)srcs[i] + (pos - offs[i]), end - pos);
-            }
-            pos = end;
-            ++i;
-        }
-        __builtin_ia32_sfence();
-    }
-    void loop(int t) {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_go.wait(lk, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
-            }
-            work(t + 1, (int)threads.size() + 1);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0) cv_done.notify_all();
-            }
-        }
-    }
-    // called by ONE thread at a time; the caller copies range 0 itself
-    void run(char* dst_, const void* const* srcs_, const size_t* offs_, int64_t count_, bool to_bf16_ = false) {
-        dst = dst_; srcs = srcs_; offs = offs_; count = count_; to_bf16 = to_bf16_;
-        const size_t total = offs_[count_];
-        if (threads.empty() || total < ((size_t)1 << 20)) { work(0, 1); return; }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            pending = (int)threads.size();
-            ++generation;
-        }
-        cv_go.notify_all();
-        work(0, (int)threads.size() + 1);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
-    }
-    void start(int n) {
-        try {
-            for (int t = (int)threads.size(); t < n - 1; ++t) threads.emplace_back([this, t] { loop(t); });
-        } catch (...) {}            // fewer threads than asked for: the ranges adapt
-    }
-    ~GatherPool() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv_go.notify_all();
-        for (auto& th : threads) th.join();
-    }
-};
 
 struct HostPipe {
     GatherPool* pool = nullptr;
@@ -185,61 +62,6 @@ static void release_hostpipe(iefvad_handle* h) {
     delete p->pool;
     delete p;
     h->hostpipe = nullptr;
-}
-
-// contiguous-range copy of `count` pieces into dst by up to `threads` threads (the body of iefvad_host_gather)
-static void host_gather_run(char* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int threads) {
-    std::vector<size_t> off((size_t)count + 1);
-    off[0] = 0;
-    for (int64_t i = 0; i < count; ++i) off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
-    const size_t total = off[(size_t)count];
-    int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    if (total < ((size_t)4 << 20)) nt = 1;
-    auto run = [&](int64_t a, int64_t b) {
-        for (int64_t i = a; i < b; ++i)
-            if (nbytes[i]) stream_copy(dst + off[(size_t)i], (const char*)srcs[i], nbytes[i]);
-        __builtin_ia32_sfence();
-    };
-    if (nt == 1) { run(0, count); return; }
-    std::vector<int64_t> cut((size_t)nt + 1, count);
-    cut[0] = 0;
-    int k = 1;
-    for (int64_t i = 0; i < count && k < nt; ++i)
-        if (off[(size_t)i + 1] >= total / nt * k) cut[(size_t)k++] = i + 1;
-    std::vector<std::thread> pool;
-    try {
-        for (int t = 1; t < nt; ++t)
-            if (cut[(size_t)t + 1] > cut[(size_t)t]) pool.emplace_back(run, cut[(size_t)t], cut[(size_t)t + 1]);
-    } catch (...) {
-        for (auto& th : pool) th.join();
-        run(cut[1], count);
-        run(0, cut[1]);
-        return;
-    }
-    run(0, cut[1]);
-    for (auto& th : pool) th.join();
-}
-
-// the staging form of wire_dtype = BF16 as an entry of its own (what the copy threads of the list walk run): fp32 pieces in, one
-// contiguous bf16 stream out
-extern "C" int iefvad_host_gather_bf16(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
-    if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather_bf16: null argument");
-    if (count == 0) return 0;
-    for (int64_t i = 0; i < count; ++i) {
-        if (nbytes[i] && !srcs[i]) return fail("iefvad_host_gather_bf16: srcs[%lld] is null", (long long)i);
-        if (nbytes[i] % 64) return fail("iefvad_host_gather_bf16: nbytes[%lld] = %zu is not a multiple of 64 (16 fp32 values)", (long long)i, nbytes[i]);
-    }
-    try {
-        std::vector<size_t> off((size_t)count + 1);
-        off[0] = 0;
-        for (int64_t i = 0; i < count; ++i) off[(size_t)i + 1] = off[(size_t)i] + nbytes[i];
-        GatherPool pool;
-        pool.start(threads < 1 ? 1 : (threads > 16 ? 16 : threads));
-        pool.run((char*)dst, srcs, off.data(), count, true);
-    } catch (const std::exception& e) {
-        return fail("iefvad_host_gather_bf16: %s", e.what());
-    }
-    return 0;
 }
 
 extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, const void* const* ev_rows, int32_t in_dtype,
@@ -308,18 +130,23 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
 
     HIP_TRY(hipSetDevice(h->device));
     if (!h->hostpipe) {
+        // built completely or not at all: a handle never keeps a HostPipe with missing streams / events
         h->hostpipe = new (std::nothrow) HostPipe();
         if (!h->hostpipe) return fail("iefvad_forward_videos_host: out of host memory");
-        HostPipe& p = *h->hostpipe;
-        HIP_TRY(hipStreamCreateWithFlags(&p.copy_stream, hipStreamNonBlocking));
-        for (int s = 0; s < HostPipe::kSlots; ++s) {
-            HIP_TRY(hipEventCreateWithFlags(&p.sent[s], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&p.used[s], hipEventDisableTiming));
+        HostPipe& np = *h->hostpipe;
+        hipError_t ce = hipStreamCreateWithFlags(&np.copy_stream, hipStreamNonBlocking);
+        for (int s = 0; s < HostPipe::kSlots && ce == hipSuccess; ++s) {
+            ce = hipEventCreateWithFlags(&np.sent[s], hipEventDisableTiming);
+            if (ce == hipSuccess) ce = hipEventCreateWithFlags(&np.used[s], hipEventDisableTiming);
         }
-        HIP_TRY(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
-        for (int l = 0; l < HostPipe::kLanes; ++l) {
-            HIP_TRY(hipStreamCreateWithFlags(&p.lane[l], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&p.lane_done[l], hipEventDisableTiming));
+        if (ce == hipSuccess) ce = hipEventCreateWithFlags(&np.ready, hipEventDisableTiming);
+        for (int l = 0; l < HostPipe::kLanes && ce == hipSuccess; ++l) {
+            ce = hipStreamCreateWithFlags(&np.lane[l], hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipEventCreateWithFlags(&np.lane_done[l], hipEventDisableTiming);
+        }
+        if (ce != hipSuccess) {
+            release_hostpipe(h);
+            return fail("iefvad_forward_videos_host: creating the internal streams / events failed: %s", hipGetErrorString(ce));
         }
     }
     HostPipe& p = *h->hostpipe;
@@ -355,7 +182,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         p.workspace_bytes = need_ws + need_ws / 8;
     }
 
-    // ---- worker: stage batch k into pinned slot k % 2 as soon as the copies of batch k - 2 have left it
+    // ---- worker: stage batch k into pinned slot k % kSlots as soon as the copies of batch k - kSlots have left it
     const int nb = (int)batches.size();
     std::mutex mu;
     std::condition_variable cv;
@@ -385,6 +212,21 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         }
     };
     std::thread worker;
+    // whatever leaves this scope -- a return, an exception of the host-side tables -- releases and joins the worker first
+    // (a joinable std::thread that is destroyed calls std::terminate: an abort across the ABI)
+    struct WorkerGuard {
+        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& abort_all; int& issued; int release;
+        ~WorkerGuard() {
+            if (!t.joinable()) return;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                abort_all = true;
+                issued = release;
+            }
+            cv.notify_all();
+            t.join();
+        }
+    } guard{worker, mu, cv, abort_all, issued, nb + HostPipe::kSlots};
     bool threaded = nb > 1;
     if (threaded) {
         try {
@@ -408,7 +250,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         }
     }
 
-    // ---- this thread: copies on the copy stream, forwards on the caller's stream
+    // ---- this thread: copies on the copy stream, forwards on the two internal lane streams
     int rc = 0;
     hipError_t he = hipEventRecord(p.ready, stream);             // inputs of this call must not overtake what the caller enqueued before
     if (he == hipSuccess) he = hipStreamWaitEvent(p.copy_stream, p.ready, 0);
@@ -430,7 +272,7 @@ extern "C" int iefvad_forward_videos_host(iefvad_handle* h, const void* const* i
         }
         const double t1 = trace ? now_us() : 0.0;
         const size_t bytes = (size_t)b.rows * wire_row_bytes;
-        he = hipStreamWaitEvent(p.copy_stream, p.used[s], 0);    // the forward of batch k - 2 has read dev_in[s]
+        he = hipStreamWaitEvent(p.copy_stream, p.used[s], 0);    // the forward of batch k - kSlots has read dev_in[s]
         for (int m = 0; m < 2 && he == hipSuccess; ++m)
             he = hipMemcpyAsync(p.dev_in[s][m], p.pinned[s][m], bytes, hipMemcpyHostToDevice, p.copy_stream);
         if (he == hipSuccess) he = hipEventRecord(p.sent[s], p.copy_stream);

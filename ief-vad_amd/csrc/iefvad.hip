@@ -1818,45 +1818,7 @@ extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side of the whole-video path: gather the videos' rows into one (pinned) staging buffer
-// ------------------------------------------------------------------------------------------------
-// Copy with non-temporal stores: the destination is a pinned staging buffer that only the DMA engine reads next, so its lines need
-// neither be fetched for ownership nor stay in the CPU caches (a plain memcpy of the 890 MB of an XD-sized list moves 2.7 GB
-// through the memory controllers, this 1.8 GB -- and the H2D copy of the previous batch is reading the same DRAM meanwhile).
-static void stream_copy(char* d, const char* s, size_t n) {
-    typedef long long v4 __attribute__((vector_size(32)));
-    typedef long long v4u __attribute__((vector_size(32), aligned(1)));
-    if (n < 4096) { memcpy(d, s, n); return; }
-    size_t head = (32 - ((uintptr_t)d & 31)) & 31;
-    memcpy(d, s, head);
-    d += head; s += head; n -= head;
-    const size_t body = n & ~(size_t)127;
-    for (size_t i = 0; i < body; i += 128) {
-        const v4 a = *(const v4u*)(s + i), b = *(const v4u*)(s + i + 32), c = *(const v4u*)(s + i + 64), e = *(const v4u*)(s + i + 96);
-        __builtin_nontemporal_store(a, (v4*)(d + i));
-        __builtin_nontemporal_store(b, (v4*)(d + i + 32));
-        __builtin_nontemporal_store(c, (v4*)(d + i + 64));
-        __builtin_nontemporal_store(e, (v4*)(d + i + 96));
-    }
-    memcpy(d + body, s + body, n - body);
-}
-
-static void host_gather_run(char* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int threads);
-
-extern "C" int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads) {
-    if (count < 0 || (count > 0 && (!dst || !srcs || !nbytes))) return fail("iefvad_host_gather: null argument");
-    if (count == 0) return 0;
-    for (int64_t i = 0; i < count; ++i)
-        if (nbytes[i] && !srcs[i]) return fail("iefvad_host_gather: srcs[%lld] is null", (long long)i);
-    try {
-        host_gather_run((char*)dst, srcs, nbytes, count, threads);
-    } catch (const std::exception& e) {
-        return fail("iefvad_host_gather: %s", e.what());
-    }
-    return 0;
-}
-
+#include "hostgather.h"
 #include "hostpipe.h"
 
 extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,

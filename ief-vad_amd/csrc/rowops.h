@@ -37,7 +37,9 @@ struct LnArgs {
 // stand-alone kernel and every fused epilogue agree bit for bit.
 __device__ __forceinline__ float ln_hsum(f32x4 t) { return (t[0] + t[1]) + (t[2] + t[3]); }
 
-__device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const float* b, int lane, float eps) {
+// centre the row in place and return 1 / sqrt(var + eps): THE statistics of a LayerNorm row -- ln_row and the backward kernel
+// (backward.h: iefvad_layernorm_bwd_kernel recomputes instead of storing them) share these operations, so both see the same bits
+__device__ __forceinline__ float ln_center_rstd(f32x4 (&v)[3], float eps) {
     const float mean = wave_sum(ln_hsum((v[0] + v[1]) + v[2])) * (1.0f / IEF_D);
     const f32x4 m4 = {mean, mean, mean, mean};
 #pragma unroll
@@ -46,7 +48,11 @@ __device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const floa
     sq = v[1] * v[1] + sq;
     sq = v[2] * v[2] + sq;
     const float var = wave_sum(ln_hsum(sq)) * (1.0f / IEF_D);
-    const float rstd = 1.0f / sqrtf(var + eps);
+    return 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void ln_row(f32x4 (&v)[3], const float* g, const float* b, int lane, float eps) {
+    const float rstd = ln_center_rstd(v, eps);
     const f32x4 r4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {

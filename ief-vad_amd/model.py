@@ -156,6 +156,7 @@ class _TrainForward(torch.autograd.Function):
             raise RuntimeError("iefvad_train_forward: " + _lib.last_error())
         ctx.model, ctx.ws, ctx.B, ctx.mask = model, ws, B, mask
         ctx.params = params
+        ctx.set_materialize_grads(False)     # backward takes None as "no gradient": no zero-filled [B,T,768] tensors for unused outputs
         return tuple(res[k] for k in OUTPUT_KEYS)
 
     @staticmethod

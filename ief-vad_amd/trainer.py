@@ -52,10 +52,11 @@ def _nan_rule(x: torch.Tensor) -> torch.Tensor:
 
 
 def train_step(model, optimizer, img: torch.Tensor, ev: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor,
-               noise_model: str = "StudentT", lambda_reg: float = 1.0, lambda_kl: float = 1.0, nan_to_num: bool = True
-               ) -> Dict[str, torch.Tensor]:
+               noise_model: str = "StudentT", lambda_reg: float = 1.0, lambda_kl: float = 1.0, nan_to_num: bool = True,
+               want_terms: bool = True) -> Optional[Dict[str, torch.Tensor]]:
     """One optimiser step on a device batch; returns the eight loss terms (`losses.TERMS`) as 0-dim device tensors -- nothing
-    is read back to the host."""
+    is read back to the host -- or None with `want_terms=False` (the loops ask for them only on the steps they log:
+    ucf_train.py:108-128 prints every `print_steps` samples)."""
     model.train()
     if nan_to_num:
         img, ev = _nan_rule(img), _nan_rule(ev)
@@ -65,6 +66,8 @@ def train_step(model, optimizer, img: torch.Tensor, ev: torch.Tensor, labels: to
     optimizer.zero_grad()
     total.backward()
     optimizer.step()
+    if not want_terms:
+        return None
     with torch.no_grad():
         terms = losses.training_losses({k: v.detach() for k, v in out.items()}, labels, lengths, noise_model, nu, lambda_reg, lambda_kl)
     return terms
@@ -111,9 +114,10 @@ def train_paired(args, model, normal_loader, abnormal_loader, test_loader, label
             ev = torch.cat([n_ev, a_ev], dim=0).to(device)
             lengths = torch.cat([n_len, a_len], dim=0).to(device)
             labels = get_batch_label(list(n_lab) + list(a_lab), prompt_text, label_map).to(device)
-            terms = train_step(model, optimizer, img, ev, labels, lengths, args.noise_model, 1.0, 1.0)
             step = i * normal_loader.batch_size * 2                                    # ucf_train.py:42,106
-            if step % args.print_steps == 0 and step != 0:
+            due = step % args.print_steps == 0 and step != 0
+            terms = train_step(model, optimizer, img, ev, labels, lengths, args.noise_model, 1.0, 1.0, want_terms=due)
+            if due:
                 rec = {f'train/loss_{k}' if k != 'total' else 'train/loss': float(v) for k, v in terms.items()}
                 auc, ap = harness.ucf_test(args, model, test_loader, args.visual_length, prompt_text, gt, device,   # ucf_train.py:130-139
                                            vis=False, batch_chunks=eval_batch_chunks)
@@ -143,10 +147,11 @@ def train_single(args, model, train_loader, test_loader, label_map, device, gt: 
     for e in range(args.max_epoch):
         for i, (img, ev, text_labels, lengths) in enumerate(train_loader):
             labels = get_batch_label(list(text_labels), prompt_text, label_map).to(device)
-            terms = train_step(model, optimizer, img.to(device), ev.to(device), labels, lengths.to(device), "StudentT", 0.01, 0.01,
-                               nan_to_num=False)                                        # xd_train.py has no NaN rule
             step = i * train_loader.batch_size
-            if step % args.print_steps == 0 and step != 0:
+            due = step % args.print_steps == 0 and step != 0
+            terms = train_step(model, optimizer, img.to(device), ev.to(device), labels, lengths.to(device), "StudentT", 0.01, 0.01,
+                               nan_to_num=False, want_terms=due)                        # xd_train.py has no NaN rule
+            if due:
                 rec = {f'train/loss_{k}' if k != 'total' else 'train/loss': float(v) for k, v in terms.items()}
                 auc, ap = harness.xd_test(args, model, test_loader, args.visual_length, prompt_text, gt, device, label_map,   # xd_train.py:102-112
                                           vis=False, batch_chunks=eval_batch_chunks)

@@ -186,8 +186,10 @@ int iefvad_forward_videos(iefvad_handle* h, const void* img_rows, const void* ev
 /* The whole evaluation LIST in one call: host rows in, per-snippet results on the device.  Replaces the Python loop around
  * iefvad_forward_videos (one iteration per video in the reference, /root/reference/test.py:76-121; one per packed batch in this
  * package until round 3): the library cuts the list into passes of >= batch_chunks chunks (whole videos; 0 = 128), a worker thread
- * gathers the rows of pass k + 1 into pinned staging (host_threads copy threads, 0 = 4) while this thread sends pass k on an
- * internal copy stream and enqueues its forward on `stream`; results land in list order.
+ * gathers the rows of the next passes into a ring of four pinned staging slots (host_threads copy threads, 0 = 8, at most 16) while
+ * this thread sends pass k on an internal copy stream and enqueues its forward on one of TWO internal non-blocking compute streams
+ * (alternating; both wait for what `stream` held at entry, and `stream` waits for both before the call returns); results land in
+ * list order.
  *   img_rows, ev_rows   HOST arrays of nvideos HOST pointers: video v's [lengths[v], D] feature rows of `in_dtype`, contiguous
  *                       (e.g. the first lengths[v] rows of the zero-padded tensor a DataLoader delivers)
  *   wire_dtype          the element type the rows cross PCIe in: `in_dtype` (the rows as they are), or IEFVAD_IN_BF16 for F32 rows

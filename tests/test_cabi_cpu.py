@@ -201,3 +201,19 @@ def test_host_gather_bf16_rounds_as_torch_does(lib):
     nb = (C.c_size_t * 1)(100)
     assert lib.iefvad_host_gather_bf16(raw.ctypes.data, ptrs, nb, 1, 2) != 0 and "multiple of 64" in L.last_error()
     assert lib.iefvad_host_gather_bf16(None, None, None, 2, 2) != 0 and "null" in L.last_error()
+
+
+def test_host_gather_code_is_clean_under_thread_and_address_sanitizers(tmp_path):
+    """tests/cabi/Makefile: ief-vad_amd/csrc/hostgather.h (GatherPool, iefvad_host_gather, iefvad_host_gather_bf16 -- the host
+    threading code of the whole-video path, the very header libiefvad.so is built from) compiled by gcc with -fsanitize=thread and
+    with -fsanitize=address,undefined into a CPU-only stress driver: the entry points on ragged / empty / unaligned pieces with
+    1..16 threads, and 1,000 jobs on one persistent pool that GROWS between jobs while the previous job's tables are already freed
+    (a thread created by a later start() must not run an earlier job).  Any sanitizer report fails the run."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("g++ / make not available")
+    cabi = os.path.join(ROOT, "tests", "cabi")
+    r = subprocess.run(["make", "-C", cabi, f"OUT={tmp_path}", "check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("hostgather_san: all checks passed") == 2

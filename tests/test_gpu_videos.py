@@ -234,6 +234,22 @@ def test_host_list_entry_equals_forward_videos(compute, batch_chunks):
         model.forward_videos_host(padded_i, padded_e[:-1], lengths)
 
 
+def test_host_list_copy_pool_grows_between_calls():
+    """ADVICE round 4 (csrc/hostgather.h): one handle, `host_threads` 2, then 8, then 16, on a list whose passes are large enough
+    (> 1 MB of rows per modality) for the pool to split them -- threads added by the later calls must start at the pool's current
+    generation, not re-run the earlier call's (freed) tables.  Every call's vectors equal `forward_videos` bit for bit."""
+    lengths = [700, 1500, 300, 1024, 90, 2000, 513, 256, 1200, 800]
+    vids = videos(lengths, seed=31)
+    model, _ = make_model("f32", outputs="scores")
+    padded_i = [torch.from_numpy(harness.process_split(v[0], 256)[0]) for v in vids]
+    padded_e = [torch.from_numpy(harness.process_split(v[1], 256)[0]) for v in vids]
+    want = ragged(model, vids)
+    for threads in (2, 8, 16, 3):
+        got = model.forward_videos_host(padded_i, padded_e, lengths, batch_chunks=8, host_threads=threads)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (threads, k)
+
+
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
 def test_host_list_passes_closed_at_one_round_of_row_blocks(compute):
     """A list long enough (31 k rows, 140 chunks) that the walk closes passes by ROWS: a row-compressed pass stops before its row set
