@@ -35,6 +35,7 @@
 #include "loss.h"
 #include "gemm_split_tn.h"
 #include "backward.h"
+#include "metrics.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -129,6 +130,7 @@ struct iefvad_handle {
     bf16_t* ref_w1st[IEFVAD_MAX_STEPS]; bf16_t* ref_w2st[IEFVAD_MAX_STEPS];
     struct HostPipe* hostpipe;  // staging slots, copy stream and workspace of iefvad_forward_videos_host (hostpipe.h)
     struct TrainState* train;   // records of the train-mode forwards whose backward is outstanding (train.h)
+    const float* row_scale[2];  // set for the duration of one iefvad_forward_scaled call: per-row input scales (image, event), nullable
 };
 static const int kAmaxActBase = 256;   // running-max slots of the projection matrices (multi-way words); behind them the activations'
 static int amax_act_tensors(int L, int K) { return 2 + 6 * L + 2 * K + 1; }   // inputs, per layer att|x|qkv x 2 modalities, z_0..z_K, h_0..h_{K-1}
@@ -292,6 +294,17 @@ static int launch_cast(const void* in0, const void* in1, float* o0, float* o1, b
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(iefvad_cast_kernel<T>, dim3((unsigned)blocks, nsrc), dim3(256), 0, stream, (const T*)in0,
                        (const T*)in1, o0, o1, b0, b1, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int launch_cast_scaled(const void* in0, const void* in1, float* o0, float* o1, bf16_t* b0, bf16_t* b1, size_t n, const float* s0,
+                              const float* s1, hipStream_t stream) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iefvad_cast_scaled_kernel<T>, dim3((unsigned)blocks, 2), dim3(256), 0, stream, (const T*)in0, (const T*)in1, o0, o1, b0, b1,
+                       n, s0, s1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -843,6 +856,20 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
 #undef RAGGED_IN
             tm.end(e);
             HIP_TRY(hipGetLastError());
+            cur[0] = xin[0];
+            cur[1] = xin[1];
+        } else if (h->row_scale[0] || h->row_scale[1]) {
+            // iefvad_forward_scaled: the rows pass through the cast kernel whatever their type, scaled on the way (rowops.h)
+            hipEvent_t e = tm.begin(ST_CAST);
+            bf16_t* b0p = need_xb0 ? xb[0] : nullptr;
+            bf16_t* b1p = need_xb0 ? xb[1] : nullptr;
+            const float* s0 = h->row_scale[0] ? h->row_scale[0] + row0 : nullptr;
+            const float* s1 = h->row_scale[1] ? h->row_scale[1] + row0 : nullptr;
+            int rc = (in_dtype == IEFVAD_IN_F32)   ? launch_cast_scaled<float>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, s0, s1, stream)
+                     : (in_dtype == IEFVAD_IN_F16) ? launch_cast_scaled<__half>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, s0, s1, stream)
+                                                   : launch_cast_scaled<__hip_bfloat16>(pi, pe, xin[0], xin[1], b0p, b1p, R * D, s0, s1, stream);
+            tm.end(e);
+            if (rc) return rc;
             cur[0] = xin[0];
             cur[1] = xin[1];
         } else if (in_dtype == IEFVAD_IN_F32) {
@@ -1545,6 +1572,18 @@ extern "C" int iefvad_forward(iefvad_handle* h, const void* img, const void* ev,
     return forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream, tm);
 }
 
+extern "C" int iefvad_forward_scaled(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, const float* img_row_scale,
+                                     const float* ev_row_scale, void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream) {
+    if (!h) return fail("iefvad_forward_scaled: null argument");
+    if (!img_row_scale && !ev_row_scale) return iefvad_forward(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, stream);
+    Timer tm;      // direct launches: the scale vectors are per call, a cached graph would pin their addresses
+    h->row_scale[0] = img_row_scale;
+    h->row_scale[1] = ev_row_scale;
+    const int rc = forward_impl(h, img, ev, in_dtype, B, workspace, workspace_bytes, out, (hipStream_t)stream, tm);
+    h->row_scale[0] = h->row_scale[1] = nullptr;
+    return rc;
+}
+
 extern "C" int iefvad_forward_timed(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
                                     void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream_,
                                     iefvad_stage_times* times) {
@@ -1814,6 +1853,71 @@ extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg
     a.eps = (float)eps;
     const size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(iefvad_adamw_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// metric tail of the evaluation loop (metrics.h)
+// ------------------------------------------------------------------------------------------------
+static size_t mt_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t metric_layout(int64_t n, char* base, MetricWs* w) {
+    const size_t tiles = (size_t)((n + MT_TILE - 1) / MT_TILE);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += mt_align(bytes); return p; };
+    char* a = take((size_t)n * 8);
+    char* b = take((size_t)n * 8);
+    char* hist = take(tiles * MT_RADIX * 4);
+    char* bsum = take(tiles * 4);
+    char* bstart = take(tiles * 4);
+    char* ap_part = take(tiles * 8);
+    char* tail = take(16);
+    if (w) {
+        w->a = (unsigned long long*)a; w->b = (unsigned long long*)b; w->hist = (unsigned*)hist; w->bsum = (unsigned*)bsum;
+        w->bstart = (unsigned*)bstart; w->ap_part = (double*)ap_part; w->auc_num = (unsigned long long*)tail; w->flags = (unsigned*)(tail + 8);
+    }
+    return off;
+}
+
+extern "C" size_t iefvad_auc_ap_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return metric_layout(n, nullptr, nullptr);
+}
+
+extern "C" int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int64_t n, int32_t repeat, double* auc, double* ap,
+                             void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!scores || !gt_frames || !workspace || (!auc && !ap)) return fail("iefvad_auc_ap: null argument");
+    if (n <= 0 || repeat <= 0) return fail("iefvad_auc_ap: n = %lld, repeat = %d", (long long)n, repeat);
+    if ((unsigned long long)n * (unsigned long long)repeat >= (1ull << 32))
+        return fail("iefvad_auc_ap: n * repeat = %llu frames do not fit the 32-bit frame counters", (unsigned long long)n * (unsigned long long)repeat);
+    if (((uintptr_t)workspace & 255) != 0) return fail("iefvad_auc_ap: the workspace must be 256-byte aligned");
+    MetricWs w;
+    const size_t need = metric_layout(n, (char*)workspace, &w);
+    if (workspace_bytes < need) return fail("iefvad_auc_ap: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles = (int)((n + MT_TILE - 1) / MT_TILE);
+    HIP_TRY(hipMemsetAsync(w.auc_num, 0, 16, stream));
+    hipLaunchKernelGGL(iefvad_metric_pairs_kernel, dim3((unsigned)((n + MT_THREADS - 1) / MT_THREADS)), dim3(MT_THREADS), 0, stream, scores,
+                       (const unsigned char*)gt_frames, (long long)n, (int)repeat, w.a, w.flags);
+    unsigned long long* src = w.a;
+    unsigned long long* dst = w.b;
+    for (int pass = 0; pass < 4; ++pass) {          // the key is the upper word of a pair
+        const int shift = 32 + 8 * pass;
+        hipLaunchKernelGGL(iefvad_metric_hist_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, (long long)n, shift, w.hist, tiles);
+        hipLaunchKernelGGL(iefvad_metric_scan_kernel, dim3(1), dim3(1024), 0, stream, w.hist, (long long)tiles * MT_RADIX);
+        hipLaunchKernelGGL(iefvad_metric_scatter_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, dst, (long long)n, shift, w.hist, tiles);
+        unsigned long long* t = src; src = dst; dst = t;
+    }
+    // four passes: the sorted pairs are back in w.a, w.b is free for the two scanned columns
+    unsigned* tp_incl = (unsigned*)w.b;
+    unsigned* gstart = tp_incl + n;
+    hipLaunchKernelGGL(iefvad_metric_tile_sums_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, (long long)n, w.bsum, w.bstart);
+    hipLaunchKernelGGL(iefvad_metric_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, w.bsum, w.bstart, tiles);
+    hipLaunchKernelGGL(iefvad_metric_tile_apply_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, (long long)n, w.bsum, w.bstart, tp_incl, gstart);
+    hipLaunchKernelGGL(iefvad_metric_groups_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, (long long)n, (int)repeat, tp_incl, gstart, w.auc_num,
+                       w.ap_part);
+    hipLaunchKernelGGL(iefvad_metric_finish_kernel, dim3(1), dim3(256), 0, stream, tp_incl, (long long)n, (int)repeat, w.auc_num, w.ap_part, tiles, w.flags,
+                       auc, ap);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -233,6 +233,31 @@ __global__ __launch_bounds__(256) void iefvad_cast_kernel(const T* in0, const T*
     }
 }
 
+// The same cast with a per-ROW scale folded in (iefvad_forward_scaled: the robustness sweep's attenuated time steps,
+// /root/reference/test2.py:71-77 `x[:, idx] = x[:, idx] * 0.01`): the product is formed in fp32 and, for fp16 / bf16 sources, rounded
+// to the source type before the widening -- torch multiplies a half tensor in fp32 and stores a half tensor, and the model then
+// widens it (imf_vad.py:41-42).  A NULL scale vector, or a scale of exactly 1, leaves the row's bits alone.
+template <typename T>
+__global__ __launch_bounds__(256) void iefvad_cast_scaled_kernel(const T* in0, const T* in1, float* out0, float* out1, __bf16* ob0, __bf16* ob1,
+                                                                 size_t n, const float* s0, const float* s1) {
+    const T* in = blockIdx.y ? in1 : in0;
+    float* out = blockIdx.y ? out1 : out0;
+    __bf16* ob = blockIdx.y ? ob1 : ob0;
+    const float* sc = blockIdx.y ? s1 : s0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx * 4 < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = idx * 4;   // n is a multiple of 4, and so is the row length: the four elements share a row
+        const float f = sc ? sc[o / IEF_D] : 1.0f;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (float)in[o + e];
+            if (f != 1.0f) v[e] = (float)(T)(v[e] * f);
+        }
+        if (out) *(f32x4*)(out + o) = v;
+        if (ob) *(bf16x4_t*)(ob + o) = to_bf16x4(v);
+    }
+}
+
 // ---- running max |x| of two tensors (blockIdx.y): the raw inputs of the first projection in fp16x3 mode
 __global__ __launch_bounds__(256) void iefvad_amax_kernel(const float* in0, const float* in1, float* out0, float* out1, size_t n) {
     const float* in = blockIdx.y ? in1 : in0;

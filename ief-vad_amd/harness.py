@@ -162,33 +162,32 @@ def evaluate_scores(scores: Sequence[np.ndarray], classes: Sequence[str], gt: np
 
 
 def device_auc_ap(scores: torch.Tensor, gt: torch.Tensor, repeat: int = 16) -> Tuple[float, float]:
-    """ROC-AUC and average precision of `np.repeat(scores, repeat)` against frame-level `gt` without leaving
-    the device and without materialising the repeat (the metric tail of test.py:158-159 costs sklearn a sort
-    of 16 x N points on the host).  Ties are handled as sklearn does: thresholds are the DISTINCT score
-    values; a snippet contributes its `repeat` frames at one threshold.
-      AUC = (sum over thresholds of trapezoids) = [sum_g P_g * (N_below_g + N_g / 2)] / (P * N)
-      AP  = sum_g (R_g - R_{g-1}) * Prec_g   with groups g in decreasing score order."""
-    s = scores.reshape(-1).to(torch.float64)
-    g = gt.reshape(-1, repeat).to(torch.float64).to(s.device)
-    assert g.shape[0] == s.shape[0], "gt must hold `repeat` frames per snippet"
-    pos = g.sum(dim=1)                        # positives among this snippet's frames
-    neg = repeat - pos
-    order = torch.argsort(s, descending=True, stable=True)
-    s, pos, neg = s[order], pos[order], neg[order]
-    new_group = torch.ones_like(s, dtype=torch.bool)
-    new_group[1:] = s[1:] != s[:-1]
-    gid = torch.cumsum(new_group.to(torch.int64), 0) - 1
-    ng = int(gid[-1].item()) + 1
-    Pg = torch.zeros(ng, dtype=torch.float64, device=s.device).index_add_(0, gid, pos)
-    Ng = torch.zeros(ng, dtype=torch.float64, device=s.device).index_add_(0, gid, neg)
-    P, N = Pg.sum(), Ng.sum()
-    tp = torch.cumsum(Pg, 0)
-    fp = torch.cumsum(Ng, 0)
-    # AUC: positives of group g beat every negative in later (lower-score) groups and tie with their own
-    neg_below = N - fp
-    auc = ((Pg * (neg_below + 0.5 * Ng)).sum() / (P * N)).item()
-    prec = tp / (tp + fp)
-    ap = ((Pg / P) * prec).sum().item()
+    """ROC-AUC and average precision of `np.repeat(scores, repeat)` against frame-level `gt` -- the metric tail of
+    test.py:158-159, which costs sklearn a sort of 16 x N points on the host -- by the library's `iefvad_auc_ap`
+    (csrc/metrics.h: one radix sort of (score, positive frames of the snippet) pairs, a scan, a reduction over the tie
+    groups; the repeat is never materialised).  Ties as sklearn: thresholds are the DISTINCT score values.
+    `scores` [N] on a HIP device; `gt` [N * repeat] (any dtype, non-zero = anomalous; host or device)."""
+    from . import lib as _lib
+    import ctypes as C
+    if not scores.is_cuda:
+        raise RuntimeError("device_auc_ap runs on a HIP device only (iefvad_auc_ap); on the host use evaluate_scores (sklearn)")
+    s = scores.reshape(-1).to(torch.float32).contiguous()
+    g = torch.as_tensor(gt).reshape(-1)
+    if g.numel() != s.numel() * repeat:
+        raise ValueError("gt must hold `repeat` frames per snippet")
+    g = (g != 0).to(torch.uint8).to(s.device, non_blocking=True).contiguous()
+    lib = _lib.load_library()
+    n = s.numel()
+    with torch.cuda.device(s.device):
+        ws = torch.empty(lib.iefvad_auc_ap_workspace_bytes(n) + 256, dtype=torch.uint8, device=s.device)
+        off = (-ws.data_ptr()) % 256
+        out = torch.empty(2, dtype=torch.float64, device=s.device)
+        rc = lib.iefvad_auc_ap(C.c_void_p(s.data_ptr()), C.c_void_p(g.data_ptr()), n, repeat, C.c_void_p(out.data_ptr()),
+                               C.c_void_p(out.data_ptr() + 8), C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
+                               C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("iefvad_auc_ap: " + _lib.last_error())
+    auc, ap = out.cpu().tolist()
     return auc, ap
 
 
@@ -769,6 +768,7 @@ def evaluate_files(args, model, gt, device, dataset: Optional[str] = None, batch
         torch.cuda.synchronize(scores_dev.device)
     t1 = time.perf_counter()
     res: Dict[str, object] = {}
+    device_metrics = device_metrics and scores_dev.is_cuda      # the metric kernels are the library's; a CPU run uses sklearn below
     if device_metrics:
         roc, ap = device_auc_ap(scores_dev, torch.as_tensor(gt))
         res.update(roc=roc, ap=ap)
@@ -873,71 +873,104 @@ class SweepResult(tuple):
 class PerturbationSweep:
     """Robustness sweep over one test list, organised for the device instead of per video:
 
-      * the videos are unpacked once (shape rule and unconditional `nan_to_num` of test2.py:52-60) and packed across
-        videos into batches of >= `batch_chunks` chunks (chunks are independent batch rows);
+      * the videos are unpacked once (shape rule and unconditional `nan_to_num` of test2.py:52-60), packed across videos into
+        batches of >= `batch_chunks` chunks (chunks are independent batch rows) and UPLOADED ONCE: the packed clean features stay
+        resident on the device for all twelve levels;
       * the CLEAN pass -- identical for all twelve levels -- runs once; what later levels need from it stays on the
         device: the clean probabilities, and the per-dimension sums of the clean fusion weights;
       * a level draws its attenuated time steps with `torch.randperm(T)` once per video and modality, image first, in
-        list order -- the draw sequence of test2.py:71-77, so seeding torch reproduces the reference's subsets -- and
-        scales those rows by 0.01 inside the packed batch (every chunk of the video alike, as `x[:, idx]` does);
-      * Brier score, KL divergence, ROC-AUC / AP (`device_auc_ap`) and the weight statistics are reduced on the device
+        list order -- the draw sequence of test2.py:71-77, so seeding torch reproduces the reference's subsets -- and turns
+        them into one fp32 row-scale vector per batch and modality (0.01 at the drawn time steps of every chunk of the video, as
+        `x[:, idx]` does, 1 elsewhere) that the library applies in its input load (`iefvad_forward_scaled`): the clean
+        features are never copied or modified;
+      * the per-snippet means of the fusion weights come from the kernels (`w_i_mean`, `w_e_mean`); the full `w_i` / `w_e`
+        are read only for the per-dimension sums of `w_img_change` / `w_ev_change` (test2.py:86-87);
+      * Brier score, KL divergence, ROC-AUC / AP (`iefvad_auc_ap`) and the weight statistics are reduced on the device
         from per-snippet values and the 16-frames-per-snippet ground truth, never materialising the x16 repeat.
 
-    `model` must return the full `w_i` / `w_e` tensors (outputs="full")."""
+    On a HIP device `model` should be built with outputs="weights" (or "full").  With a CPU `device` (plumbing runs with a CPU
+    model) the scale is applied to a copy with torch ops and the metrics come from sklearn as in test2.py:105-106."""
 
     def __init__(self, args, model, loader, gt, device, batch_chunks: int = 64, repeat: int = 16):
         self.model, self.device, self.repeat = model, torch.device(device), repeat
         self.T = T = args.visual_length
-        self.videos: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
+        videos: List[Tuple[torch.Tensor, torch.Tensor, int]] = []
         for item in loader:
             img, ev, n = item[0].squeeze(0), item[1].squeeze(0), int(item[3])
             if n < T:
                 img, ev = img.unsqueeze(0), ev.unsqueeze(0)
-            self.videos.append((torch.nan_to_num(img), torch.nan_to_num(ev), n))
+            videos.append((torch.nan_to_num(img), torch.nan_to_num(ev), n))
+        self.lengths = [n for _, _, n in videos]
+        self.nchunks = [int(v[0].shape[0]) for v in videos]
         self.batches: List[List[int]] = [[]]
         load = 0
-        for v, (img, _, _) in enumerate(self.videos):
+        for v, nch in enumerate(self.nchunks):
             self.batches[-1].append(v)
-            load += img.shape[0]
-            if load >= batch_chunks and v + 1 < len(self.videos):
+            load += nch
+            if load >= batch_chunks and v + 1 < len(videos):
                 self.batches.append([])
                 load = 0
-        self.total = sum(n for _, _, n in self.videos)
+        # packed batches, resident on the device: (img [C, T, D], ev [C, T, D], valid row indices)
+        self.packed = []
+        for batch in self.batches:
+            dts = {videos[v][m].dtype for v in batch for m in (0, 1)}
+            dt = torch.float32 if len(dts) > 1 else next(iter(dts))
+            img = torch.cat([videos[v][0].to(dt) for v in batch]).to(self.device)
+            ev = torch.cat([videos[v][1].to(dt) for v in batch]).to(self.device)
+            valid, off = [], 0
+            for v in batch:
+                valid.append(torch.arange(off * T, off * T + self.lengths[v]))
+                off += self.nchunks[v]
+            self.packed.append((img, ev, torch.cat(valid).to(self.device)))
+        self.total = sum(self.lengths)
         g = torch.as_tensor(np.asarray(gt)[: repeat * self.total], dtype=torch.float64).reshape(self.total, repeat)
         self.gt = g.to(self.device)
         self.pos = self.gt.sum(dim=1)                        # anomalous frames of each snippet
         self.clean_passes = 0
         self._clean = None
 
-    # one packed pass over the list; `row_scale[v]` = (image rows, event rows) to attenuate in video v, or None
-    def _pass(self, row_scale=None):
+    def _scales(self, batch, draws):
+        """Row-scale vectors [C * T] (image, event) of one packed batch for one level's draws; None for an untouched modality."""
+        out = []
+        C = sum(self.nchunks[v] for v in batch)
+        for m in (0, 1):
+            if all(draws[v][m] is None or draws[v][m].numel() == 0 for v in batch):
+                out.append(None)
+                continue
+            sc = torch.ones(C, self.T)
+            off = 0
+            for v in batch:
+                idx = draws[v][m]
+                if idx is not None and idx.numel():
+                    sc[off:off + self.nchunks[v], idx] = 0.01
+                off += self.nchunks[v]
+            out.append(sc.reshape(-1).to(self.device))
+        return out
+
+    # one packed pass over the list; `draws[v]` = (image time steps, event time steps) to attenuate in video v, or None
+    def _pass(self, draws=None):
         probs, wi_rows, we_rows = [], [], []
         wi_dim = we_dim = None
+        on_gpu = self.device.type == 'cuda'
         with torch.no_grad():
-            for batch in self.batches:
-                dts = {self.videos[v][m].dtype for v in batch for m in (0, 1)}
-                dt = torch.float32 if len(dts) > 1 else next(iter(dts))
-                img = torch.cat([self.videos[v][0].to(dt) for v in batch]).to(self.device)
-                ev = torch.cat([self.videos[v][1].to(dt) for v in batch]).to(self.device)
-                valid, off = [], 0
-                for v in batch:
-                    nch, n = self.videos[v][0].shape[0], self.videos[v][2]
-                    if row_scale is not None:
-                        for x, idx in ((img, row_scale[v][0]), (ev, row_scale[v][1])):
-                            if idx is not None and idx.numel():
-                                blk = x[off:off + nch]
-                                blk[:, idx.to(self.device)] *= 0.01
-                    valid.append(torch.arange(off * self.T, off * self.T + n, device=self.device))
-                    off += nch
-                valid = torch.cat(valid)
-                out = self.model(img, ev, None, None, None)
+            for batch, (img, ev, valid) in zip(self.batches, self.packed):
+                if draws is None:
+                    out = self.model(img, ev, None, None, None)
+                else:
+                    si, se = self._scales(batch, draws)
+                    if on_gpu:
+                        out = self.model(img, ev, None, None, None, row_scale=(si, se))
+                    else:       # CPU plumbing: the product as torch forms it on a copy (test2.py:70-77)
+                        xi = img if si is None else (img * si.reshape(-1, self.T, 1).to(img.dtype))
+                        xe = ev if se is None else (ev * se.reshape(-1, self.T, 1).to(ev.dtype))
+                        out = self.model(xi, xe, None, None, None)
                 D = out['w_i'].shape[-1]
                 probs.append(torch.sigmoid(out['logits'].reshape(-1)[valid]).float())
-                wi = out['w_i'].reshape(-1, D)[valid].float()
-                we = out['w_e'].reshape(-1, D)[valid].float()
-                wi_rows.append(wi.mean(dim=1))
-                we_rows.append(we.mean(dim=1))
-                si, se = wi.double().sum(dim=0), we.double().sum(dim=0)
+                wi = out['w_i'].reshape(-1, D)[valid]
+                we = out['w_e'].reshape(-1, D)[valid]
+                wi_rows.append(out['w_i_mean'].reshape(-1)[valid] if 'w_i_mean' in out else wi.float().mean(dim=1))
+                we_rows.append(out['w_e_mean'].reshape(-1)[valid] if 'w_e_mean' in out else we.float().mean(dim=1))
+                si, se = wi.sum(dim=0, dtype=torch.float64), we.sum(dim=0, dtype=torch.float64)
                 wi_dim = si if wi_dim is None else wi_dim + si
                 we_dim = se if we_dim is None else we_dim + se
         return {"p": torch.cat(probs), "wi_row": torch.cat(wi_rows), "we_row": torch.cat(we_rows),
@@ -949,11 +982,19 @@ class PerturbationSweep:
             self.clean_passes += 1
         return self._clean
 
+    def _auc_ap(self, p):
+        if self.device.type == 'cuda':
+            return device_auc_ap(p, self.gt, self.repeat)
+        from sklearn.metrics import average_precision_score, roc_auc_score      # test2.py:105-106
+        y = np.repeat(p.cpu().numpy(), self.repeat)
+        g = self.gt.reshape(-1).cpu().numpy()
+        return roc_auc_score(g, y), average_precision_score(g, y)
+
     def level(self, sigma_img=0, sigma_ev=0) -> SweepResult:
         c = self.clean()
         k_img, k_ev = int(self.T * sigma_img), int(self.T * sigma_ev)
         draws = []
-        for _ in self.videos:        # the reference's draw order: per video, image then event; no draw for a zero sigma
+        for _ in self.lengths:       # the reference's draw order: per video, image then event; no draw for a zero sigma
             di = torch.randperm(self.T)[:k_img] if sigma_img else None
             de = torch.randperm(self.T)[:k_ev] if sigma_ev else None
             draws.append((di, de))
@@ -964,7 +1005,7 @@ class PerturbationSweep:
         eps = 1e-8
         pc, qn = yc.clamp(eps, 1 - eps), yn.clamp(eps, 1 - eps)
         kl = (pc * torch.log(pc / qn) + (1 - pc) * torch.log((1 - pc) / (1 - qn))).mean()
-        auc, ap = device_auc_ap(n["p"], self.gt, rep)
+        auc, ap = self._auc_ap(n["p"])
         wi, we = n["wi_row"].double(), n["we_row"].double()
         P, N = self.pos.sum(), (rep - self.pos).sum()
         stats = torch.stack([brier, kl, wi.mean(), we.mean(), (wi * self.pos).sum() / P, (we * self.pos).sum() / P,

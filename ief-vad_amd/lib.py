@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IEFVAD_LIB") or os.path.join(_HERE, "libiefvad.so")      # IEFVAD_LIB: A/B builds of the same ABI (tools)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
@@ -28,7 +28,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
            "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward",
-           "iefvad_forward_videos_host", "iefvad_host_gather_bf16"]
+           "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -116,6 +116,9 @@ def load_library() -> C.CDLL:
     lib.iefvad_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_size_t, C.POINTER(Outputs), C.c_void_p]
     lib.iefvad_forward.restype = C.c_int
+    lib.iefvad_forward_scaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.POINTER(Outputs), C.c_void_p]
+    lib.iefvad_forward_scaled.restype = C.c_int
     lib.iefvad_forward_timed.argtypes = lib.iefvad_forward.argtypes + [C.POINTER(StageTimes)]
     lib.iefvad_forward_timed.restype = C.c_int
     lib.iefvad_videos_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
@@ -147,6 +150,10 @@ def load_library() -> C.CDLL:
     lib.iefvad_host_gather.restype = C.c_int
     lib.iefvad_host_gather_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]
     lib.iefvad_host_gather_bf16.restype = C.c_int
+    lib.iefvad_auc_ap_workspace_bytes.argtypes = [C.c_int64]
+    lib.iefvad_auc_ap_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_auc_ap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.iefvad_auc_ap.restype = C.c_int
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.iefvad_gemm_bias.restype = C.c_int

@@ -192,9 +192,10 @@ class MMFMIL(nn.Module):
     """Same constructor as the reference's MMFMIL (/root/reference/model/imf_vad.py:6-18).
 
     Extra, keyword-only knobs (not in the reference):
-      outputs      "full" (default; all eight tensors, the drop-in behaviour) or "scores"
+      outputs      "full" (default; all eight tensors, the drop-in behaviour), "scores"
                    (only `logits` plus the per-row means `w_i_mean`, `w_e_mean`; nothing 768-wide
-                   is written to HBM).
+                   is written to HBM) or "weights" (the scores set plus the full `w_i`, `w_e`: what the
+                   robustness sweep reads, test2.py:65-68).
       micro_batch  chunks per internal pass of the library (0 = library default).
       graph_chunks calls with B <= graph_chunks replay a cached hipGraph of the forward instead of launching its ~31
                    kernels one by one (0 = library default, 8; negative = never).  Same bits either way.
@@ -226,8 +227,8 @@ class MMFMIL(nn.Module):
         self.temporal = FusionParams(embed_dim, num_layers=args.visual_layers, num_heads=args.visual_head,
                                      num_refinement_steps=args.num_refinement_steps, lambda_ref=args.lambda_ref,
                                      noise_model=args.noise_model, nu=args.nu)
-        if outputs not in ("full", "scores"):
-            raise ValueError("outputs must be 'full' or 'scores'")
+        if outputs not in ("full", "scores", "weights"):
+            raise ValueError("outputs must be 'full', 'scores' or 'weights'")
         if compute not in _lib.COMPUTE_CODES:
             raise ValueError("compute must be 'f32', 'bf16', 'bf16x6' or 'fp16x3'")
         self.outputs = outputs
@@ -373,7 +374,11 @@ class MMFMIL(nn.Module):
         return x.contiguous()
 
     def forward(self, img_visual, ev_visual, padding_mask=None, text=None, lengths=None, return_attn=False,
-                *, timed: bool = False) -> Dict[str, torch.Tensor]:
+                *, timed: bool = False, row_scale=None) -> Dict[str, torch.Tensor]:
+        """The reference's call (imf_vad.py:40-44; `padding_mask`, `text`, `lengths`, `return_attn` accepted and ignored as there).
+        Keyword-only extras: `timed` (per-stage device times in `last_stage_times`), `row_scale=(s_img, s_ev)`: fp32 DEVICE vectors
+        of [B*T] (either may be None) that multiply the input rows inside the library's input load (`iefvad_forward_scaled`: the
+        robustness sweep's `x[:, idx] * 0.01`, test2.py:71-77, without touching the caller's tensors)."""
         self._noise_code()   # ValueError for an unsupported noise_model, as the reference raises
         if self.training:
             return self._forward_train(img_visual, ev_visual)
@@ -412,12 +417,23 @@ class MMFMIL(nn.Module):
                         res[k] = torch.empty(B, T, D, **f32)
                         setattr(o, k, res[k].data_ptr())
             else:
+                if self.outputs == "weights":       # the sweep's set (test2.py:65-68,86-87): both weight tensors, and their row means
+                    for k in ("w_i", "w_e"):
+                        res[k] = torch.empty(B, T, D, **f32)
+                        setattr(o, k, res[k].data_ptr())
                 res["w_i_mean"] = torch.empty(B, T, **f32)
                 res["w_e_mean"] = torch.empty(B, T, **f32)
                 o.w_i_mean, o.w_e_mean = res["w_i_mean"].data_ptr(), res["w_e_mean"].data_ptr()
             args = (self._handle, C.c_void_p(img.data_ptr()), C.c_void_p(ev.data_ptr()), _IN_DTYPES[img.dtype], B,
                     C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), C.byref(o), C.c_void_p(stream))
-            if timed:
+            if row_scale is not None and (row_scale[0] is not None or row_scale[1] is not None):
+                sp = []
+                for sv in row_scale:
+                    if sv is not None and (sv.dtype != torch.float32 or sv.device != device or sv.numel() != N or not sv.is_contiguous()):
+                        raise ValueError(f"row_scale vectors must be contiguous fp32 tensors of {N} elements on {device}")
+                    sp.append(C.c_void_p(sv.data_ptr()) if sv is not None else None)
+                rc = lib.iefvad_forward_scaled(*args[:5], sp[0], sp[1], *args[5:])
+            elif timed:
                 st = _lib.StageTimes()
                 rc = lib.iefvad_forward_timed(*args, C.byref(st))
                 self.last_stage_times = st.as_dict()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IEFVAD_ABI_VERSION 6
+#define IEFVAD_ABI_VERSION 7
 #define IEFVAD_MAX_LAYERS 8   /* args.visual_layers (reference default 2, parser.py:5)            */
 #define IEFVAD_MAX_STEPS 64   /* args.num_refinement_steps (reference default 10, test.py:406)    */
 
@@ -310,6 +310,31 @@ int iefvad_host_gather(void* dst, const void* const* srcs, const size_t* nbytes,
  * bf16 (sum(nbytes) / 2 bytes; round to nearest even, NaN stays NaN with its sign, overflow to +-inf -- the device's conversion).
  * This is what iefvad_forward_videos_host's copy threads run for wire_dtype = IEFVAD_IN_BF16. */
 int iefvad_host_gather_bf16(void* dst, const void* const* srcs, const size_t* nbytes, int64_t count, int32_t threads);
+
+/* iefvad_forward with a per-row scale on the INPUT features: row r of modality m enters the model as x[r] * scale_m[r] (the
+ * product rounded to the input type, as torch does for fp16 / bf16 tensors, before imf_vad.py:41-42 widens it); a NULL vector
+ * scales nothing.  This is the perturbation of the reference's robustness sweep (/root/reference/test2.py:71-77:
+ * `v_p[:, indexs] = v_p[:, indexs] * 0.01` on a random subset of time steps) folded into the input load, so the packed clean
+ * features can stay resident on the device across the sweep's twelve levels.  img_row_scale, ev_row_scale: DEVICE [B*T] fp32. */
+int iefvad_forward_scaled(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B, const float* img_row_scale,
+                          const float* ev_row_scale, void* workspace, size_t workspace_bytes, const iefvad_outputs* out, void* stream);
+
+/* ---- metric tail of the evaluation loop --------------------------------------------------------------
+ * What /root/reference/test.py:158-159 (train/ucf_test.py:153-154, train/xd_test.py:146-147) computes with sklearn on the host,
+ *     ROC1 = roc_auc_score(gt, np.repeat(ap1, 16));   AP1 = average_precision_score(gt, np.repeat(ap1, 16))
+ * on the DEVICE from the n per-snippet scores and the frame-level ground truth, without materialising the x`repeat` copy: one
+ * radix sort of n (score, positive-frames-of-the-snippet) pairs, a scan, a reduction over the tie groups.  Thresholds are the
+ * DISTINCT score values as in sklearn's _binary_clf_curve (tied snippets share one threshold; -0.0 == +0.0); the AUC numerator is
+ * accumulated exactly in 64-bit integers, the AP terms in doubles in a fixed order: deterministic, and equal to sklearn to ~1e-15.
+ *   scores      DEVICE [n] fp32 (e.g. sigmoid of iefvad_forward_videos_host's logits, or iefvad_gather_scores's output)
+ *   gt_frames   DEVICE [n * repeat] bytes, non-zero = anomalous frame (the reference's gt.npy holds 0.0 / 1.0, test.py:379)
+ *   auc, ap     DEVICE doubles, each nullable (not both); valid once `stream` has run.  A NaN score makes both NaN; only one class
+ *               in gt_frames makes *auc NaN (sklearn raises there) and, with no positive frame, *ap 0 (as sklearn returns)
+ *   workspace   DEVICE, iefvad_auc_ap_workspace_bytes(n) bytes (16 n + ~1.1 KB per 4096 snippets), 256-byte aligned
+ * n * repeat must stay below 2^32 frames.  Enqueued on `stream`; returns without synchronising. */
+size_t iefvad_auc_ap_workspace_bytes(int64_t n);
+int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int64_t n, int32_t repeat, double* auc, double* ap,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.

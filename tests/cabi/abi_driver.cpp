@@ -143,6 +143,27 @@ int main(int argc, char** argv) {
         iefvad_comm_destroy(comm);
         (void)hipFree(gathered);
     }
+    // the metric tail for a consumer without sklearn: AUC / AP of the logits against a deterministic frame-level
+    // ground truth (frame j positive iff the top three bits of j * 2654435761 mod 2^32 are zero), 16 frames per snippet
+    double h_metric[2] = {0.0, 0.0};
+    {
+        const size_t n = (size_t)B * T;
+        std::vector<uint8_t> hgt(n * 16);
+        for (size_t j = 0; j < hgt.size(); ++j) hgt[j] = (((uint32_t)j * 2654435761u) >> 29) == 0;
+        uint8_t* dgt = nullptr;
+        double* dm = nullptr;
+        void* mws = nullptr;
+        const size_t mwsb = iefvad_auc_ap_workspace_bytes((int64_t)n);
+        if (mwsb == 0) { fprintf(stderr, "iefvad_auc_ap_workspace_bytes returned 0\n"); return 7; }
+        HIPCK(hipMalloc((void**)&dgt, hgt.size())); HIPCK(hipMalloc((void**)&dm, 16)); HIPCK(hipMalloc(&mws, mwsb));
+        HIPCK(hipMemcpyAsync(dgt, hgt.data(), hgt.size(), hipMemcpyHostToDevice, stream));
+        ABICK(iefvad_auc_ap(logits, dgt, (int64_t)n, 16, dm, dm + 1, mws, mwsb, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        HIPCK(hipMemcpy(h_metric, dm, 16, hipMemcpyDeviceToHost));
+        if (!(h_metric[0] > 0.0 && h_metric[0] < 1.0 && h_metric[1] > 0.0 && h_metric[1] < 1.0)) { fprintf(stderr, "AUC %g / AP %g out of range\n", h_metric[0], h_metric[1]); return 7; }
+        (void)hipFree(dgt); (void)hipFree(dm); (void)hipFree(mws);
+    }
+    printf("metrics AUC %.15f AP %.15f\n", h_metric[0], h_metric[1]);
     printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK\n", B, L, K, st.total_ms, st.gemm_launches);
     iefvad_destroy(h);
     (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);

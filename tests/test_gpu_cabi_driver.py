@@ -43,6 +43,13 @@ def test_torch_free_c_driver_matches_python_path(tmp_path, B, compute):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_driver OK" in r.stdout
     got = np.fromfile(out, dtype=np.float32).reshape(B, 256)
+    # the metric tail the driver printed (iefvad_auc_ap on its logits) against sklearn on the same logits and the same frame rule
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    j = np.arange(B * 256 * 16, dtype=np.uint64)
+    gt = ((((j * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(29)) == 0).astype(np.float64)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("metrics AUC")][0].split()
+    y = np.repeat(got.reshape(-1), 16)
+    assert abs(float(line[2]) - roc_auc_score(gt, y)) < 1e-12 and abs(float(line[4]) - average_precision_score(gt, y)) < 1e-12
     args = argparse.Namespace(visual_layers=L, visual_head=8, num_refinement_steps=K, lambda_ref=0.5,
                               noise_model="StudentT", nu=8)
     m = iefvad_amd.MMFMIL(14, 768, 256, 768, 8, L, 8, 10, 10, "cuda", args, outputs="scores", compute=compute)

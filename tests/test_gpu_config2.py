@@ -95,26 +95,12 @@ def test_chunk_permutation_equivariance_at_scale():
     assert float((d["logits"] - d["logits"][0, 0]).abs().max()) < 1e-6
 
 
-def test_device_metric_tail_matches_sklearn_on_gpu():
-    """AUC / AP computed on the device from the gathered scores equal sklearn's on the x16 repeat."""
-    from sklearn.metrics import average_precision_score, roc_auc_score
-    rng = np.random.default_rng(9)
-    n = 69510
-    s = rng.random(n).astype(np.float32)
-    s[::7] = s[1::7][: len(s[::7])]                       # ties
-    gt = (rng.random(16 * n) < 0.2).astype(np.float64)
-    auc, ap = harness.device_auc_ap(torch.from_numpy(s).cuda(), torch.from_numpy(gt).cuda())
-    assert abs(auc - roc_auc_score(gt, np.repeat(s, 16))) < 1e-10
-    assert abs(ap - average_precision_score(gt, np.repeat(s, 16))) < 1e-10
-
-
 def test_perturbation_sweep_on_gpu_matches_reference_capture(golden_dir):
     """The robustness sweep (test2.py:35-123) through the HIP path vs the reference's own run_test capture."""
     import os
     g = np.load(os.path.join(golden_dir, "sweep_test2.npz"))
     lengths, seed = [int(v) for v in g["lengths"]], int(g["seed"])
     gt = synth.make_gt(seed, sum(lengths))
-    model = gpu_model(synth.make_state_dict(int(g["wseed"])))
 
     def loader():
         for i, n in enumerate(lengths):
@@ -124,13 +110,53 @@ def test_perturbation_sweep_on_gpu_matches_reference_capture(golden_dir):
             yield torch.tensor(ci).unsqueeze(0), torch.tensor(ce).unsqueeze(0), ("Normal",), torch.tensor([n])
 
     args = argparse.Namespace(visual_length=256)
-    torch.manual_seed(0)
-    cache = {}
-    for tag, kw in (("img02", dict(sigma_img=0.2, sigma_ev=0)), ("ev03", dict(sigma_img=0, sigma_ev=0.3))):
-        r = harness.run_perturbation_test(args, model, loader(), gt, "cuda:0", clean_cache=cache, **kw)
-        assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), tag
-        assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
-        assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
+    for outputs in ("weights", "full"):      # "weights": logits + w_i / w_e + their row means from the kernels; "full": the drop-in dict
+        model = gpu_model(synth.make_state_dict(int(g["wseed"])), outputs=outputs)
+        torch.manual_seed(0)
+        cache = {}
+        for tag, kw in (("img02", dict(sigma_img=0.2, sigma_ev=0)), ("ev03", dict(sigma_img=0, sigma_ev=0.3))):
+            r = harness.run_perturbation_test(args, model, loader(), gt, "cuda:0", clean_cache=cache, **kw)
+            assert np.allclose([float(x) for x in r[:10]], g[tag + "_scalars"], rtol=0, atol=2e-6), (outputs, tag)
+            assert np.abs(r[10].numpy() - g[tag + "_w_img_change"]).max() < 2e-6
+            assert np.abs(r[11].numpy() - g[tag + "_w_ev_change"]).max() < 2e-6
+        sweep = cache["sweep"]
+        assert sweep.clean_passes == 1 and all(t[0].is_cuda for t in sweep.packed)      # uploaded once, clean pass once
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16", "bf16x6"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_row_scale_in_the_input_load_equals_scaling_the_tensor(compute, dtype):
+    """`iefvad_forward_scaled` (test2.py:71-77's `x[:, idx] = x[:, idx] * 0.01` folded into the library's input load): the forward on
+    (x, row_scale) must equal, bit for bit, the forward on the tensor torch scaled itself -- fp32 rows multiply in fp32, fp16
+    rows are rounded to fp16 after the product as torch stores them; one modality scaled, the other untouched (NULL vector);
+    B = 9 chunks so the bf16x6 handle runs its split kernels and the bf16 one spans a partial tile."""
+    model = gpu_model(synth.make_state_dict(5), outputs="scores", compute=compute)
+    model.to("cuda:0").eval()
+    B = 9
+    img, ev = synth.make_inputs(77, B)
+    img, ev = torch.from_numpy(img).to(dtype).cuda(), torch.from_numpy(ev).to(dtype).cuda()
+    gen = torch.Generator().manual_seed(1)
+    sc = torch.ones(B, 256)
+    for b in range(B):
+        sc[b, torch.randperm(256, generator=gen)[:77]] = 0.01
+    sc = sc.reshape(-1).cuda()
+    with torch.no_grad():
+        got = model(img, ev, None, None, None, row_scale=(sc, None))
+        scaled = img.clone()
+        rows = sc.reshape(B, 256) != 1
+        scaled[rows] = scaled[rows] * 0.01
+        want = model(scaled, ev, None, None, None)
+        clean = model(img, ev, None, None, None)
+        got_e = model(img, ev, None, None, None, row_scale=(None, sc))
+        scaled_e = ev.clone()
+        scaled_e[rows] = scaled_e[rows] * 0.01
+        want_e = model(img, scaled_e, None, None, None)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+        assert torch.equal(got_e[k], want_e[k]), k
+    assert not torch.equal(got["logits"], clean["logits"])
+    with pytest.raises(ValueError, match="row_scale"):
+        model(img, ev, None, None, None, row_scale=(sc[:-1], None))
 
 
 def test_full_config4_batch_properties():
