@@ -95,6 +95,11 @@ def parse(argv=None):
                    help="launcher self-test for machines without a GPU (tests/test_bench_launcher_cpu.py): NO forward runs; "
                         "every rank fabricates the scores of its shard as a ramp of global snippet indices on the CPU and the "
                         "launch -> shard -> gather (gloo) -> max-over-ranks -> JSON path is exercised; `value` is null")
+    p.add_argument("--plumbing-comm", default="none", choices=["none", "fail", "hang"],
+                   help="--plumbing-only rehearsal of the gather-transport handshake (harness.ScoreComm): the library's communicator "
+                        "create fails ('fail') or never returns ('hang') on the LAST rank; every rank must end up on the "
+                        "torch.distributed transport, with the reason in the line's `gather` field, and the job must finish")
+    p.add_argument("--plumbing-comm-timeout", type=float, default=5.0)
     return p.parse_args(argv)
 
 
@@ -563,6 +568,16 @@ def main():
     gatherer = None
     if world > 1 and backend == "nccl":
         gatherer = harness.ScoreGatherer(dev)
+    elif world > 1 and not gpu and a.plumbing_comm != "none":
+        def fake_create(ident, nranks, r):
+            if r == nranks - 1:
+                if a.plumbing_comm == "hang":
+                    time.sleep(3600)
+                raise RuntimeError("injected failure on the last rank")
+            return 0xC0FFEE
+        hooks = {"version": lambda: 22205, "unique_id": lambda: b"\0" * 128, "create": fake_create, "destroy": lambda h: None,
+                 "nranks": lambda h: world}
+        gatherer = harness.ScoreGatherer("cpu", create_timeout=a.plumbing_comm_timeout, _hooks=hooks)
     elif world > 1:
         gatherer = harness.ScoreGatherer("cpu", prefer_library=False)
         gatherer.label = "torch.distributed gloo (scores staged through the host)"

@@ -1055,42 +1055,79 @@ class ScoreComm:
     once per process over an initialised torch.distributed group, whose store only carries the 128-byte unique id
     from rank 0 to the other ranks.  The gather itself is `iefvad_gather_scores` on the caller's HIP stream."""
 
-    def __init__(self, device, group=None):
+    CREATE_TIMEOUT_S = 120.0      # iefvad_comm_create is a collective (ncclCommInitRank): a rank that never arrives must not hang the job
+
+    def __init__(self, device, group=None, create_timeout: Optional[float] = None, _hooks: Optional[dict] = None):
+        """`_hooks` (tests only: tests/test_bench_launcher_cpu.py rehearses the failure paths on CPU ranks) replaces the four
+        library calls of the handshake -- {'version', 'unique_id', 'create', 'destroy', 'nranks'} -- with callables."""
         import ctypes as C
+        import threading
         import torch.distributed as dist
         from . import lib as _lib
         self._lib = _lib.load_library()
         self._last_error = _lib.last_error
+        self._hooks = _hooks or {}
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        timeout = self.CREATE_TIMEOUT_S if create_timeout is None else float(create_timeout)
         # every failure below is made SYMMETRIC: a rank that raised alone would leave the others blocked in a collective.
         # First of all: can EVERY rank bind librccl?  (iefvad_comm_create is itself a collective -- ncclCommInitRank -- so a
         # rank that cannot even dlopen the library must be found out before anybody enters it.)
-        ver = torch.tensor([int(self._lib.iefvad_rccl_version())], dtype=torch.int64, device=self.device)
+        version = self._hooks.get('version', lambda: int(self._lib.iefvad_rccl_version()))
+        ver = torch.tensor([int(version())], dtype=torch.int64, device=self.device)
         dist.all_reduce(ver, op=dist.ReduceOp.MIN, group=group)
         if int(ver.item()) <= 0:
             raise RuntimeError("librccl cannot be bound on at least one rank (iefvad_rccl_version() == 0)")
         self.rccl_version = int(ver.item())
         ident = [None]
         if self.rank == 0:
-            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-            if self._lib.iefvad_comm_unique_id(buf) != 0:
-                ident = ["iefvad_comm_unique_id: " + self._last_error()]      # a str instead of the id: everybody raises
+            if 'unique_id' in self._hooks:
+                ident = [self._hooks['unique_id']()]
             else:
-                ident = [bytes(buf.raw)]
+                buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+                if self._lib.iefvad_comm_unique_id(buf) != 0:
+                    ident = ["iefvad_comm_unique_id: " + self._last_error()]      # a str instead of the id: everybody raises
+                else:
+                    ident = [bytes(buf.raw)]
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if not isinstance(ident[0], bytes):
             raise RuntimeError(str(ident[0]))
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            rc = self._lib.iefvad_comm_create(C.c_char_p(ident[0]), self.world, self.rank, C.byref(self._h))
-        err = "" if rc == 0 else "iefvad_comm_create: " + self._last_error()
+        # the collective create runs on a helper thread and is waited for with a deadline: if a peer died or never enters
+        # ncclCommInitRank, this rank gives up after `timeout` seconds, reports failure in the all-reduce below -- which its
+        # peers reach the same way -- and the job continues on torch.distributed's transport instead of hanging
+        box = {}
+
+        def create():
+            try:
+                if 'create' in self._hooks:
+                    box['h'] = self._hooks['create'](ident[0], self.world, self.rank)
+                    box['rc'] = 0
+                else:
+                    with torch.cuda.device(self.device):
+                        box['rc'] = self._lib.iefvad_comm_create(C.c_char_p(ident[0]), self.world, self.rank, C.byref(self._h))
+                    box['err'] = "" if box['rc'] == 0 else "iefvad_comm_create: " + self._last_error()     # thread-local message: read it here
+            except Exception as e:       # noqa: BLE001 -- reported through the all-reduce like any other failure
+                box['rc'], box['err'] = 1, f"iefvad_comm_create: {e}"
+
+        th = threading.Thread(target=create, name="iefvad_comm_create", daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            rc, err = 1, f"iefvad_comm_create did not return within {timeout:.0f} s (a peer never entered the collective)"
+            self._abandoned = th       # still inside the collective: its handle is never used, the daemon thread dies with the process
+        else:
+            rc, err = box.get('rc', 1), box.get('err', "")
+            if rc == 0 and 'h' in box:
+                self._h = box['h']
         bad = torch.tensor([1 if rc != 0 else 0], dtype=torch.int32, device=self.device)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
         if int(bad.item()) != 0:
-            self.close()
+            if rc == 0:
+                self.close()
+            self._h = None
             raise RuntimeError(err or "iefvad_comm_create failed on another rank")
-        self.nranks = int(self._lib.iefvad_comm_nranks(self._h))      # what RCCL reports
+        self.nranks = int(self._hooks['nranks'](self._h)) if 'nranks' in self._hooks else int(self._lib.iefvad_comm_nranks(self._h))      # what RCCL reports
 
     def gather(self, local: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
         import ctypes as C
@@ -1111,7 +1148,10 @@ class ScoreComm:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.iefvad_comm_destroy(self._h)
+            if 'destroy' in getattr(self, "_hooks", {}):
+                self._hooks['destroy'](self._h)
+            else:
+                self._lib.iefvad_comm_destroy(self._h)
             self._h = None
 
 
@@ -1166,11 +1206,11 @@ class ScoreGatherer:
     LIB = "iefvad_gather_scores (libiefvad -> librccl: ncclAllGather, or grouped ncclSend/ncclRecv for unequal shards, on the forward's stream)"
     TORCH = "torch.distributed all_gather_into_tensor"
 
-    def __init__(self, device, group=None, prefer_library: bool = True):
+    def __init__(self, device, group=None, prefer_library: bool = True, create_timeout: Optional[float] = None, _hooks=None):
         self.group, self.comm = group, None
         if prefer_library:
             try:
-                self.comm = ScoreComm(device, group)
+                self.comm = ScoreComm(device, group, create_timeout, _hooks)
                 self.label = self.LIB
             except Exception as e:                  # symmetric (see ScoreComm.__init__): every rank lands here or none
                 self.label = f"{self.TORCH} (library gather unavailable: {e})"

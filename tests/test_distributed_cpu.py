@@ -65,7 +65,7 @@ def _worker(rank, world, port, out_path):
     calls = []
 
     class Fake:
-        def __init__(self, device, group=None):
+        def __init__(self, device, group=None, *a, **k):
             self.nranks = world
 
         def gather(self, scores, counts=None):

@@ -61,11 +61,15 @@ def test_auc_ap_on_signed_tiny_and_saturated_scores():
     s[2::50] = -0.0
     s[3::70] = 1e-42
     s[4::90] = -1e-42
-    s[7::1000] = np.inf
-    s[9::1000] = -np.inf
     gt = (rng.random(16 * n) < 0.3).astype(np.float64)
     auc, ap = auc_ap(s, gt)
     a0, p0 = sk(s, gt)
+    assert abs(auc - a0) < 1e-12 and abs(ap - p0) < 1e-12
+    # +-inf (sklearn refuses them): they must rank above / below every finite score, i.e. like +-3e38 stand-ins
+    s[7::1000] = np.inf
+    s[9::1000] = -np.inf
+    auc, ap = auc_ap(s, gt)
+    a0, p0 = sk(np.where(np.isinf(s), np.sign(s) * np.float32(3e38), s), gt)
     assert abs(auc - a0) < 1e-12 and abs(ap - p0) < 1e-12
 
 
