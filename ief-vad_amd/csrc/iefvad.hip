@@ -764,6 +764,103 @@ static int launch_proj(const Proj& p, int compute, bool use_split, int rows, hip
     return launch_gemm_b(g, p.nz, stream, tm, stage);
 }
 
+// ---- the four row-block launches of the bf16 mode: shared by forward_pass and by the unit entry iefvad_rowblock_unit, so a unit test
+// runs the very kernel symbol, grid and LDS size the forward uses at that row count
+static int launch_inproj_chain(iefvad_handle* h, int l, const void* const A[2], bool a_fp32, bf16_t* const C[2], int rows, hipStream_t stream, Timer& tm) {
+    InProjChainArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    for (int m = 0; m < 2; ++m) {
+        ia.p[m].A = A[m];
+        ia.p[m].stream = h->iproj_stream[m][l]; ia.p[m].bias = h->in_b[m][l]; ia.p[m].C = C[m];
+    }
+    // q is pre-scaled for the softmax by log2(e)/sqrt(96): both attention kernels use exp2
+    ia.M = rows; ia.alpha = (1.0f / sqrtf((float)IEF_DH)) * 1.4426950408889634f; ia.wave_stride = (unsigned)wstream_wave_stride_bytes(IC_NPASS);
+#ifdef IC_DIAG
+    { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_IC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ia.diag = dg; }
+#endif
+    hipEvent_t e = tm.begin(ST_QKV);
+    if (a_fp32) hipLaunchKernelGGL(iefvad_inproj_chain_f32in_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
+    else hipLaunchKernelGGL(iefvad_inproj_chain_bf16_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int launch_outproj_ln_chain(iefvad_handle* h, int l, bool whiten, const bf16_t* const A[2], const float* const R[2], float* const y[2],
+                                   bf16_t* const yb[2], int rows, hipStream_t stream, Timer& tm) {
+    OutLnChainArgs oa;
+    memset(&oa, 0, sizeof(oa));
+    for (int m = 0; m < 2; ++m) {
+        OutLnChainProblem& q = oa.p[m];
+        q.A = A[m]; q.stream = h->oproj_stream[m][l]; q.bias = h->out_b[m][l]; q.R = R[m];
+        q.g1 = h->norm_w[m][l]; q.b1 = h->norm_b[m][l];
+        if (whiten) { q.g2 = h->whiten_w[m]; q.b2 = h->whiten_b[m]; }
+        q.y = y[m];
+        q.yb = yb[m];
+    }
+    oa.M = rows; oa.eps = 1e-5f; oa.wave_stride = (unsigned)wstream_wave_stride_bytes();
+    { static const int st = [] { const char* v = getenv("IEFVAD_OL_STAGGER"); return v ? atoi(v) : 0; }(); oa.stagger = st; }
+#ifdef OC_DIAG
+    { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_OC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); oa.diag = dg; }
+#endif
+    // from two blocks per workgroup on: the persistent kernel, one workgroup per CU, the next block's image fetched during the
+    // LayerNorm epilogue (outproj_ln_pchain_bf16.h; same bits); IEFVAD_PERSIST=0 keeps the one-block-per-workgroup kernels (A/B)
+    static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
+    const int gx = h->num_cus / 2;
+    hipEvent_t e = tm.begin(ST_OUT);
+    if (persist && rows / OC_BM >= 2 * gx)
+        hipLaunchKernelGGL(iefvad_outproj_ln_pchain_bf16_kernel, dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
+    else
+        hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// `ha` arrives with its tensors filled in; the stream, scalars and the kernel choice are set here
+static int launch_heads_chain(iefvad_handle* h, HeadsChainArgs& ha, int rows, float factor, hipStream_t stream, Timer& tm) {
+    for (int m = 0; m < 2; ++m) ha.bias[m] = h->head_b[m];
+    ha.stream = h->heads_stream;
+    ha.M = rows; ha.factor = factor; ha.eps = h->cfg.epsilon; ha.wave_stride = (unsigned)heads_stream_wave_stride_bytes();
+#ifdef HC_DIAG
+    { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_HC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ha.diag = dg; }
+#endif
+    // from two blocks per workgroup on: the persistent kernel (heads_pchain_bf16.h: one workgroup per CU and column third, both
+    // images by LDS-DMA under the previous block's epilogue / the first part of phase 2; same bits); IEFVAD_PERSIST=0: A/B
+    static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
+    const int gx = h->num_cus / HC_THIRDS;
+    hipEvent_t e = tm.begin(ST_HEAD);
+    if (persist && rows / HC_BM >= 2 * gx)
+        hipLaunchKernelGGL(iefvad_heads_pchain_bf16_kernel, dim3(gx, HC_THIRDS), dim3(512), HP_LDS_BYTES, stream, ha);
+    else
+        hipLaunchKernelGGL(iefvad_heads_chain_bf16_kernel, dim3(rows / HC_BM, HC_THIRDS), dim3(512), HC_LDS_BYTES, stream, ha);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int launch_refine_chain(iefvad_handle* h, const float* z_in, float* z_out, float* logits, int rows, hipStream_t stream, Timer& tm) {
+    const int K = h->cfg.num_steps;
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.z_in = z_in; ca.stream = h->chain_stream; ca.cls_w = h->cls_w; ca.cls_b = h->cls_b;
+    ca.z_out = z_out;           // may be z_in (in place): a workgroup reads its 64 rows before it writes them
+    ca.logits = logits;
+    ca.M = rows; ca.K = K; ca.lambda = h->cfg.lambda_ref; ca.wave_stride = (unsigned)chain_wave_stride_bytes(K);
+#ifdef RC_DIAG
+    { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_RC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ca.diag = dg; }
+#endif
+    hipEvent_t e = tm.begin(ST_REFINE);
+    hipLaunchKernelGGL(iefvad_refine_chain_bf16_kernel, dim3(rows / RC_BM), dim3(64 * RC_NW), RC_LDS_BYTES, stream, ca);
+    tm.end(e);
+    tm.gemm_launches += 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One pass of the valid rows of whole videos (iefvad_forward_videos): where the packed rows of the pass's chunks come from and
 // where its per-row results go.
 struct RaggedPass {
@@ -919,22 +1016,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         for (int l = 0; l < L; ++l) {
             Proj p;
             if (ip_chain) {
-                InProjChainArgs ia;
-                memset(&ia, 0, sizeof(ia));
-                for (int m = 0; m < 2; ++m) {
-                    ia.p[m].A = (l == 0) ? (const void*)cur[m] : (const void*)xb[m];
-                    ia.p[m].stream = h->iproj_stream[m][l]; ia.p[m].bias = h->in_b[m][l]; ia.p[m].C = qkvb[m];
-                }
-                ia.M = rows; ia.alpha = qscale * 1.4426950408889634f; ia.wave_stride = (unsigned)wstream_wave_stride_bytes(IC_NPASS);
-#ifdef IC_DIAG
-                { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_IC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ia.diag = dg; }
-#endif
-                hipEvent_t e = tm.begin(ST_QKV);
-                if (l == 0) hipLaunchKernelGGL(iefvad_inproj_chain_f32in_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
-                else hipLaunchKernelGGL(iefvad_inproj_chain_bf16_kernel, dim3(rows / IC_BM, 2), dim3(512), IC_LDS_BYTES, stream, ia);
-                tm.end(e);
-                tm.gemm_launches += 1;
-                HIP_TRY(hipGetLastError());
+                const void* ipA[2] = {(l == 0) ? (const void*)cur[0] : (const void*)xb[0], (l == 0) ? (const void*)cur[1] : (const void*)xb[1]};
+                if (int rc = launch_inproj_chain(h, l, ipA, l == 0, qkvb, rows, stream, tm)) return rc;
             }
             memset(&p, 0, sizeof(p));
             p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
@@ -994,33 +1077,9 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             // structure (outproj_ln_chain_bf16.h); same bits as the GEMM + LayerNorm kernels
             const bool ln_fused = bf && !h->no_ln_fusion && rows % OC_BM == 0 && (rows / OC_BM) * 2 >= h->rowblock_min_wgs;
             if (ln_fused) {
-                OutLnChainArgs oa;
-                memset(&oa, 0, sizeof(oa));
-                for (int m = 0; m < 2; ++m) {
-                    OutLnChainProblem& q = oa.p[m];
-                    q.A = attb[m]; q.stream = h->oproj_stream[m][l]; q.bias = h->out_b[m][l]; q.R = cur[m];
-                    q.g1 = h->norm_w[m][l]; q.b1 = h->norm_b[m][l];
-                    if (l == L - 1) { q.g2 = h->whiten_w[m]; q.b2 = h->whiten_b[m]; }
-                    q.y = (l < L - 1) ? xbuf[m] : nullptr;      // fp32 rows are only the next layer's residual
-                    q.yb = xb[m];
-                }
-                oa.M = rows; oa.eps = 1e-5f; oa.wave_stride = (unsigned)wstream_wave_stride_bytes();
-                { static const int st = [] { const char* v = getenv("IEFVAD_OL_STAGGER"); return v ? atoi(v) : 0; }(); oa.stagger = st; }
-#ifdef OC_DIAG
-                { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_OC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); oa.diag = dg; }
-#endif
-                // from two blocks per workgroup on: the persistent kernel, one workgroup per CU, the next block's image fetched during the
-                // LayerNorm epilogue (outproj_ln_pchain_bf16.h; same bits); IEFVAD_PERSIST=0 keeps the one-block-per-workgroup kernels (A/B)
-                static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
-                const int gx = h->num_cus / 2;
-                e = tm.begin(ST_OUT);
-                if (persist && rows / OC_BM >= 2 * gx)
-                    hipLaunchKernelGGL(iefvad_outproj_ln_pchain_bf16_kernel, dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
-                else
-                    hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
-                tm.end(e);
-                tm.gemm_launches += 1;
-                HIP_TRY(hipGetLastError());
+                const bf16_t* oA[2] = {attb[0], attb[1]};
+                float* oy[2] = {(l < L - 1) ? xbuf[0] : nullptr, (l < L - 1) ? xbuf[1] : nullptr};      // fp32 rows are only the next layer's residual
+                if (int rc = launch_outproj_ln_chain(h, l, l == L - 1, oA, cur, oy, xb, rows, stream, tm)) return rc;
                 cur[0] = xbuf[0];
                 cur[1] = xbuf[1];
                 continue;
@@ -1097,8 +1156,7 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
         if (heads_rows) {
             HeadsChainArgs ha;
             memset(&ha, 0, sizeof(ha));
-            for (int m = 0; m < 2; ++m) { ha.A[m] = xtb[m]; ha.bias[m] = h->head_b[m]; }
-            ha.stream = h->heads_stream;
+            for (int m = 0; m < 2; ++m) ha.A[m] = xtb[m];
             ha.mu[0] = out->image_mu ? mu_i : nullptr;
             ha.lv[0] = out->image_logvar ? lv_i : nullptr;
             ha.mu[1] = out->event_mu ? mu_e : nullptr;
@@ -1109,22 +1167,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             ha.zb = chain ? nullptr : zb;
             const bool means = wim_out || wem_out;
             ha.nsum_part = means ? ybuf[0] : nullptr;        // y is dead after the last LayerNorm: 48 of its 768 floats per row
-            ha.M = rows; ha.factor = factor; ha.eps = c.epsilon; ha.wave_stride = (unsigned)heads_stream_wave_stride_bytes();
-#ifdef HC_DIAG
-            { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_HC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ha.diag = dg; }
-#endif
-            // from two blocks per workgroup on: the persistent kernel (heads_pchain_bf16.h: one workgroup per CU and column third, both
-            // images by LDS-DMA under the previous block's epilogue / the first part of phase 2; same bits); IEFVAD_PERSIST=0: A/B
-            static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
-            const int gx = h->num_cus / HC_THIRDS;
-            hipEvent_t e = tm.begin(ST_HEAD);
-            if (persist && rows / HC_BM >= 2 * gx)
-                hipLaunchKernelGGL(iefvad_heads_pchain_bf16_kernel, dim3(gx, HC_THIRDS), dim3(512), HP_LDS_BYTES, stream, ha);
-            else
-                hipLaunchKernelGGL(iefvad_heads_chain_bf16_kernel, dim3(rows / HC_BM, HC_THIRDS), dim3(512), HC_LDS_BYTES, stream, ha);
-            tm.end(e);
-            tm.gemm_launches += 1;
-            HIP_TRY(hipGetLastError());
+            if (int rc = launch_heads_chain(h, ha, rows, factor, stream, tm)) return rc;
+            hipEvent_t e;
             if (means) {
                 e = tm.begin(ST_FUSION);
                 hipLaunchKernelGGL(iefvad_rowmean_finish_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, stream, ha.nsum_part,
@@ -1166,22 +1210,8 @@ static int forward_pass(iefvad_handle* h, const void* pi_, const void* pe_, int3
             HIP_TRY(hipGetLastError());
         }
 
-        if (chain) {
-            ChainArgs ca;
-            memset(&ca, 0, sizeof(ca));
-            ca.z_in = z; ca.stream = h->chain_stream; ca.cls_w = h->cls_w; ca.cls_b = h->cls_b;
-            ca.z_out = out->fused ? z : nullptr;        // in place: a workgroup reads its 64 rows before it writes them
-            ca.logits = logits;
-            ca.M = rows; ca.K = K; ca.lambda = c.lambda_ref; ca.wave_stride = (unsigned)chain_wave_stride_bytes(K);
-#ifdef RC_DIAG
-            { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_RC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); ca.diag = dg; }
-#endif
-            hipEvent_t e = tm.begin(ST_REFINE);
-            hipLaunchKernelGGL(iefvad_refine_chain_bf16_kernel, dim3(rows / RC_BM), dim3(64 * RC_NW), RC_LDS_BYTES, stream, ca);
-            tm.end(e);
-            tm.gemm_launches += 1;
-            HIP_TRY(hipGetLastError());
-        }
+        if (chain)
+            if (int rc = launch_refine_chain(h, z, out->fused ? z : nullptr, logits, rows, stream, tm)) return rc;
 
         // 4. K refinement steps z <- z - lambda * (W2 relu(W1 z + b1) + b2) (imf_vad.py:146-149); the state z stays fp32
         for (int k = 0; k < K && !chain; ++k) {
@@ -1924,6 +1954,62 @@ extern "C" int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int6
 
 #include "hostgather.h"
 #include "hostpipe.h"
+
+// One production row-block kernel of the bf16 mode on caller-supplied rows (include/iefvad.h): the launch helpers forward_pass uses.
+extern "C" int iefvad_rowblock_unit(iefvad_handle* h, int32_t stage, int32_t layer, int32_t rows, const iefvad_unit_io* io, void* stream_) {
+    if (!h || !io) return fail("iefvad_rowblock_unit: null argument");
+    if (!h->weights_set) return fail("iefvad_rowblock_unit: weights not set");
+    if (h->cfg.compute != IEFVAD_COMPUTE_BF16) return fail("iefvad_rowblock_unit: the row-block kernels belong to compute = BF16 (got %d)", h->cfg.compute);
+    if (rows <= 0 || rows % 64) return fail("iefvad_rowblock_unit: rows = %d must be a positive multiple of 64", rows);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int L = h->cfg.num_layers, K = h->cfg.num_steps;
+    Timer tm;
+    auto aligned = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    switch (stage) {
+    case IEFVAD_UNIT_INPROJ: {
+        if (layer < 0 || layer >= L) return fail("iefvad_rowblock_unit: layer %d of %d", layer, L);
+        if (!h->iproj_stream[0][layer]) return fail("iefvad_rowblock_unit: in_proj streams are not packed on this handle");
+        const void* A[2] = {io->x[0], io->x[1]};
+        bf16_t* C[2] = {(bf16_t*)io->y[0], (bf16_t*)io->y[1]};
+        for (int m = 0; m < 2; ++m)
+            if (!A[m] || !C[m] || !aligned(A[m]) || !aligned(C[m])) return fail("iefvad_rowblock_unit: INPROJ needs x[m] and y[m], 16-byte aligned");
+        return launch_inproj_chain(h, layer, A, layer == 0, C, rows, stream, tm);
+    }
+    case IEFVAD_UNIT_OUTPROJ_LN: {
+        if (layer < 0 || layer >= L) return fail("iefvad_rowblock_unit: layer %d of %d", layer, L);
+        if (!h->oproj_stream[0][layer]) return fail("iefvad_rowblock_unit: out_proj streams are not packed on this handle");
+        const bf16_t* A[2] = {(const bf16_t*)io->x[0], (const bf16_t*)io->x[1]};
+        const float* R[2] = {io->resid[0], io->resid[1]};
+        float* y[2] = {(float*)io->y[0], (float*)io->y[1]};
+        bf16_t* yb[2] = {(bf16_t*)io->yb[0], (bf16_t*)io->yb[1]};
+        for (int m = 0; m < 2; ++m)
+            if (!A[m] || !R[m] || (!y[m] && !yb[m]) || !aligned(A[m]) || !aligned(R[m]) || !aligned(y[m]) || !aligned(yb[m]))
+                return fail("iefvad_rowblock_unit: OUTPROJ_LN needs x[m], resid[m] and y[m] or yb[m], 16-byte aligned");
+        return launch_outproj_ln_chain(h, layer, layer == L - 1, A, R, y, yb, rows, stream, tm);
+    }
+    case IEFVAD_UNIT_HEADS: {
+        if (!h->heads_stream) return fail("iefvad_rowblock_unit: the heads stream is not packed on this handle");
+        if (!io->x[0] || !io->x[1] || !io->z || !aligned(io->x[0]) || !aligned(io->x[1]) || !aligned(io->z))
+            return fail("iefvad_rowblock_unit: HEADS needs x[0], x[1] and z, 16-byte aligned");
+        HeadsChainArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        for (int m = 0; m < 2; ++m) {
+            ha.A[m] = (const bf16_t*)io->x[m];
+            ha.mu[m] = io->mu[m]; ha.lv[m] = io->logvar[m]; ha.n[m] = io->w[m];
+        }
+        ha.z = io->z;
+        const float factor = (h->cfg.noise_model == IEFVAD_NOISE_STUDENT_T) ? (h->cfg.nu + 1.0f) / h->cfg.nu : 1.0f;
+        return launch_heads_chain(h, ha, rows, factor, stream, tm);
+    }
+    case IEFVAD_UNIT_REFINE: {
+        if (K < 1 || !h->chain_stream) return fail("iefvad_rowblock_unit: the refinement chain needs K >= 1 (K = %d)", K);
+        if (!io->x[0] || !io->logits || !aligned(io->x[0]) || !aligned(io->z)) return fail("iefvad_rowblock_unit: REFINE needs x[0] (z_0) and logits");
+        return launch_refine_chain(h, (const float*)io->x[0], io->z, io->logits, rows, stream, tm);
+    }
+    default:
+        return fail("iefvad_rowblock_unit: unknown stage %d", stage);
+    }
+}
 
 extern "C" int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                                 int32_t compute, void* stream) {

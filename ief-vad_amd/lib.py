@@ -28,7 +28,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
            "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward",
-           "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled"]
+           "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled", "iefvad_rowblock_unit"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -94,6 +94,15 @@ def build_library(force: bool = False) -> str:
     return LIB_PATH
 
 
+class UnitIO(C.Structure):
+    """iefvad_unit_io (include/iefvad.h)."""
+    _fields_ = [("x", C.c_void_p * 2), ("resid", C.c_void_p * 2), ("y", C.c_void_p * 2), ("yb", C.c_void_p * 2), ("mu", C.c_void_p * 2),
+                ("logvar", C.c_void_p * 2), ("w", C.c_void_p * 2), ("z", C.c_void_p), ("logits", C.c_void_p)]
+
+
+UNIT_INPROJ, UNIT_OUTPROJ_LN, UNIT_HEADS, UNIT_REFINE = 0, 1, 2, 3
+
+
 def load_library() -> C.CDLL:
     """dlopen libiefvad.so and declare prototypes.  Raises if the library or a symbol is missing."""
     global _lib
@@ -154,6 +163,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_auc_ap_workspace_bytes.restype = C.c_size_t
     lib.iefvad_auc_ap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.iefvad_auc_ap.restype = C.c_int
+    lib.iefvad_rowblock_unit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(UnitIO), C.c_void_p]
+    lib.iefvad_rowblock_unit.restype = C.c_int
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.iefvad_gemm_bias.restype = C.c_int

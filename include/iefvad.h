@@ -336,6 +336,37 @@ size_t iefvad_auc_ap_workspace_bytes(int64_t n);
 int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int64_t n, int32_t repeat, double* auc, double* ap,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- unit entry for the bf16 mode's row-block kernels (per-kernel parity tests) -----------------------------------------
+ * Launches ONE production kernel of compute = IEFVAD_COMPUTE_BF16 -- the symbol, grid and LDS size iefvad_forward uses at that row
+ * count (the persistent variants from two 64-row blocks per workgroup on) -- on caller-supplied DEVICE rows, with the handle's
+ * weights.  `rows` is a multiple of 64; both modalities ride one launch as in the forward.  Stages and the fields they read:
+ *   IEFVAD_UNIT_INPROJ      layer l: x[m] = the layer's input rows [rows,768] (fp32 for l == 0, bf16 otherwise) ->
+ *                           y[m] = bf16 q | k | v, head-major [3][8 heads][rows][96], q pre-scaled by log2(e)/sqrt(96)
+ *                           (/root/reference/model/imf_vad.py:115,121: nn.MultiheadAttention's packed in_proj)
+ *   IEFVAD_UNIT_OUTPROJ_LN  layer l: x[m] = attention output bf16 [rows,768], resid[m] = the layer's fp32 input rows ->
+ *                           LayerNorm(resid + x W_o^T + b_o) (imf_vad.py:116,122), and for l == L-1 the whitening LayerNorm
+ *                           behind it (:117,:123): y[m] fp32 and / or yb[m] bf16 [rows,768] (each nullable, not both)
+ *   IEFVAD_UNIT_HEADS       x[m] = whitened rows bf16 [rows,768] -> mu[m], logvar[m], w[m] (each nullable) and the fused z
+ *                           (imf_vad.py:125-144)
+ *   IEFVAD_UNIT_REFINE      x[0] = z_0 fp32 [rows,768] -> z = z_K (nullable), logits [rows] (imf_vad.py:146-150)
+ * All pointers 16-byte aligned.  Enqueued on `stream`. */
+#define IEFVAD_UNIT_INPROJ 0
+#define IEFVAD_UNIT_OUTPROJ_LN 1
+#define IEFVAD_UNIT_HEADS 2
+#define IEFVAD_UNIT_REFINE 3
+typedef struct iefvad_unit_io {
+    const void* x[2];
+    const float* resid[2];
+    void* y[2];
+    void* yb[2];
+    float* mu[2];
+    float* logvar[2];
+    float* w[2];
+    float* z;
+    float* logits;
+} iefvad_unit_io;
+int iefvad_rowblock_unit(iefvad_handle* h, int32_t stage, int32_t layer, int32_t rows, const iefvad_unit_io* io, void* stream);
+
 /* Stand-alone dense projection C[M,N] = A[M,K] * W[N,K]^T + bias[N] on the library's GEMM
  * kernels (unit tests and the roofline micro-benchmark).  M % 128 == 0, N % 128 == 0, K % 64 == 0.
  * compute = IEFVAD_COMPUTE_F32: A and W are fp32; IEFVAD_COMPUTE_BF16: A and W are bf16 (same shapes);
