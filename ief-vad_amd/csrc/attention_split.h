@@ -61,6 +61,8 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (
     if constexpr (!F16) { ATS_MFMA(xp[NP - 1], yp[0], c); ATS_MFMA(xp[0], yp[NP - 1], c); ATS_MFMA(xp[1], yp[1], c); } \
     ATS_MFMA(xp[1], yp[0], c); ATS_MFMA(xp[0], yp[1], c); ATS_MFMA(xp[0], yp[0], c)
 
+__device__ __forceinline__ int wave_id_of(int t) { return t >> 6; }
+
 template <bool F16, bool RG = false>
 __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs) {
     constexpr int NP = F16 ? 2 : 3;
@@ -90,15 +92,22 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     const int i = lane & 31, h = lane >> 5;
     const int q0 = qhalf * 128 + wave * 32;
 
-    // staging map: a 64-row x 24-chunk (4 floats) tile; thread t moves rows (t >> 3) + 32 (j & 1), chunks (t & 7) + 8 (j >> 1),
-    // j = 0..5: eight lanes cover one 128-byte line, and every offset is a constant added to two per-thread bases
-    const int srow0 = t >> 3, sch0 = t & 7;
-    const float* gsrc = qkv + (RG ? 0 : (size_t)srow0 * (3 * IEF_D)) + sch0 * 4;     // RG: the row is clamped per load
+    // staging map: a 64-row x 24-chunk (4 floats) tile; thread t moves rows srow + 32 (j & 1), chunks (t & 7) + 8 (j >> 1),
+    // j = 0..5: eight lanes cover one 128-byte line, and every offset is a constant added to two per-thread bases.
+    // WHICH row an 8-lane group takes depends on the plane pitch, so that the four 64-byte row segments a half-wave writes with
+    // one ds_write_b64 fall into four disjoint 16-bank ranges: V planes (192-byte rows = 48 banks) take consecutive rows
+    // (0, 48, 32, 16); K planes (208-byte rows = 52 banks: consecutive rows start at banks 0, 52, 40, 28 and overlap in 12 banks --
+    // 3.8e7 conflict cycles per launch in rounds 2 - 4) take rows R, R + 4, R + 8, R + 12 (52 x 4 = 208 = 16 mod 64: banks 0, 16, 32, 48).
+    const int sch0 = t & 7;
+    const int srow_v = t >> 3;
+    const int srow_k = 16 * (wave_id_of(t) >> 1) + 2 * (wave_id_of(t) & 1) + 4 * ((t >> 3) & 3) + ((t >> 5) & 1);
+    const float* gsrc_v = qkv + (RG ? 0 : (size_t)srow_v * (3 * IEF_D)) + sch0 * 4;     // RG: the row is clamped per load
+    const float* gsrc_k = qkv + (RG ? 0 : (size_t)srow_k * (3 * IEF_D)) + sch0 * 4;
     f32x4 stg[6];
     // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
 #define ATS_LOAD(ti)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
-        stg[j] = *(const f32x4*)(gsrc + (size_t)(RG ? ATS_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + srow0)         \
+        stg[j] = *(const f32x4*)(((ti) < 4 ? gsrc_k : gsrc_v) + (size_t)(RG ? ATS_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + ((ti) < 4 ? srow_k : srow_v)) \
                                                       : ((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +       \
                                  ((ti) < 4 ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
     // split the staged fp32 chunks and write the three bf16 plane images of tile ti into buffer `buf`
@@ -108,7 +117,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
         if constexpr (F16) { _Pragma("unroll") for (int e = 0; e < 4; ++e) sp.r[e] = stg[j][e] * qs; }        \
         else sp.r = stg[j];                                                                                   \
         const int rowlen = (ti) < 4 ? ATS_KROW : ATS_VROW, plane = (ti) < 4 ? ATS_KPLANE : ATS_VPLANE;        \
-        bf16_t* dst = kvs + (buf) * ATS_BUF + (srow0 + 32 * (j & 1)) * rowlen + sch0 * 4 + 32 * (j >> 1);     \
+        bf16_t* dst = kvs + (buf) * ATS_BUF + (((ti) < 4 ? srow_k : srow_v) + 32 * (j & 1)) * rowlen + sch0 * 4 + 32 * (j >> 1); \
         _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                      \
             unsigned d0, d1;                                                                                  \
             if constexpr (F16) sp.plane_f16(d0, d1, p < NP - 1); else sp.plane(d0, d1, p < NP - 1);           \

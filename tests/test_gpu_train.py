@@ -128,6 +128,50 @@ def test_bf16x6_backward_on_the_split_kernel_at_a_batch_that_fills_its_grid():
     assert differ > len(sd64) // 2
 
 
+@pytest.mark.parametrize("compute", ["bf16x6", "f32"])
+def test_gradients_at_the_benched_batch_equal_the_sum_over_sub_batches(compute):
+    """bench.py times the training step at the reference's UCF batch -- 128 chunks = 32,768 rows (/root/reference/train/ucf_train.py:44-48
+    with parser.py's batch_size 64 per loader), K = 10 -- where the weight-gradient products run split-K over 16 - 32 row slices, the
+    split NT / TN kernels at full grids and the attention products over 1,024 (chunk, head) pairs per launch; no fixture reaches that
+    size (the reference's fp64 autograd at B = 128 is out of reach for a test).  A scalar that is a SUM OVER ROWS of the outputs
+    makes every parameter gradient additive over chunks, so the B = 128 gradient must equal the sum, in fp64, of the gradients of
+    sixteen B = 8 sub-batches -- each of which is the size the fp64-autograd test above pins -- to the fp32 gate; and the step
+    must reproduce its bits from run to run at this size too.  p = 0 (the dropout generator indexes elements by their position in
+    the batch, so a sub-batch would draw another mask)."""
+    L, K, B, SUB = 2, 10, 128, 8
+    img, ev, _, _ = synth.make_train_batch(91, B)
+    img, ev = torch.from_numpy(img).cuda(), torch.from_numpy(ev).cuda()
+
+    def scalar(o):
+        return (o["logits"].sum() + 0.5 * (o["image_mu"] * o["event_logvar"]).sum() + 0.25 * (o["event_mu"] * o["image_logvar"]).sum()
+                + 0.125 * (o["fused"] * o["w_i"]).sum())
+
+    model, _ = make_model(6, L, K, "StudentT", 8, compute, 0.0)
+    model.train()
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        scalar(model(img, ev, None, None, None)).backward()
+        runs.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n                  # fixed-order reductions at full grids
+    total = {n: torch.zeros_like(g, dtype=torch.float64) for n, g in runs[0].items()}
+    for b0 in range(0, B, SUB):
+        model.zero_grad(set_to_none=True)
+        scalar(model(img[b0:b0 + SUB].contiguous(), ev[b0:b0 + SUB].contiguous(), None, None, None)).backward()
+        for n, p in model.named_parameters():
+            total[n] += p.grad.detach().double()
+    worst = 0.0
+    for n, want in total.items():
+        got = runs[0][n].double()
+        mx = float(want.abs().max())
+        err = (got - want).abs()
+        ok = err <= 1e-4 * want.abs() + 2e-6 * mx
+        assert bool(ok.all()), (compute, n, float(err.max()), mx)
+        worst = max(worst, float(err.max()) / max(mx, 1e-30))
+    print(f"B = 128 gradients vs the sum over sixteen B = 8 sub-batches ({compute}): worst max-relative error {worst:.2e}")
+
+
 def test_gradients_are_bit_reproducible_and_accumulate():
     """No atomics in any reduction: two runs give the same bits; a second backward into existing .grad accumulates, as autograd does."""
     _, m1, _, _ = run_case("k2_student8")
