@@ -4,7 +4,7 @@ A thin Python host over `libiefvad.so` (hand-written HIP kernels behind the C AB
 include/iefvad.h).  Importing the package does not load the library; the first forward does, and
 fails loudly if the library is missing -- there is no CPU fallback.
 """
-from . import harness, lib, losses, synth, trainer  # noqa: F401
+from . import harness, layers, lib, losses, module, synth, trainer  # noqa: F401
 from .model import MMFMIL, OUTPUT_KEYS  # noqa: F401
 
-__all__ = ["MMFMIL", "OUTPUT_KEYS", "harness", "lib", "losses", "synth", "trainer"]
+__all__ = ["MMFMIL", "OUTPUT_KEYS", "harness", "layers", "lib", "losses", "module", "synth", "trainer"]

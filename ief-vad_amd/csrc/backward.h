@@ -44,6 +44,9 @@ struct BgemmArgs {
     long long a1, a2, b1, b2, c1, c2;     // batch z = z1 * nz2 + z2: operand offsets z1 * x1 + z2 * x2 (floats)
     int nz2;
     float alpha;
+    // epilogue extras (zero / null in every product of the backward pass): v = act(alpha * acc + bias[j] + R[i, j])
+    const float* bias;       // nullable: [N], broadcast over the rows (and over the batch)
+    int act;                 // 0 none; 1 QuickGELU v * sigmoid(1.702 v) (/root/reference/model/module.py:15-17); 2 ELU (layers.py:43-44)
 };
 
 #define BG_BM 128
@@ -159,8 +162,11 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
             const int m = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
             const size_t o = coff + (size_t)m * a.ldc + n0 + 32 * b + i;
             float v = a.alpha * acc[b][r];
+            if (a.bias) v += a.bias[n0 + 32 * b + i];
             if (a.R) v += a.R[o];
             if (a.G) v = a.G[o] > 0.f ? v : 0.f;
+            if (a.act == 1) v = v * (1.0f / (1.0f + expf(-1.702f * v)));
+            else if (a.act == 2) v = v > 0.f ? v : expm1f(v);
             a.C[o] = v;
         }
 }

@@ -1952,6 +1952,7 @@ extern "C" int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int6
     return 0;
 }
 
+#include "vadclip.h"
 #include "hostgather.h"
 #include "hostpipe.h"
 

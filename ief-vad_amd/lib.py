@@ -28,7 +28,10 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
            "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward",
-           "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled", "iefvad_rowblock_unit"]
+           "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled", "iefvad_rowblock_unit",
+           "iefvad_similarity_adj", "iefvad_similarity_adj_workspace_bytes", "iefvad_distance_adj", "iefvad_gcn_forward",
+           "iefvad_gcn_workspace_bytes", "iefvad_gat_forward", "iefvad_gat_workspace_bytes", "iefvad_resblock_forward",
+           "iefvad_resblock_workspace_bytes"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -103,6 +106,12 @@ class UnitIO(C.Structure):
 UNIT_INPROJ, UNIT_OUTPROJ_LN, UNIT_HEADS, UNIT_REFINE = 0, 1, 2, 3
 
 
+class ResblockWeights(C.Structure):
+    """iefvad_resblock_weights (include/iefvad.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln_1_w", "ln_1_b", "ln_2_w", "ln_2_b", "c_fc_w",
+                                          "c_fc_b", "c_proj_w", "c_proj_b")]
+
+
 def load_library() -> C.CDLL:
     """dlopen libiefvad.so and declare prototypes.  Raises if the library or a symbol is missing."""
     global _lib
@@ -165,6 +174,25 @@ def load_library() -> C.CDLL:
     lib.iefvad_auc_ap.restype = C.c_int
     lib.iefvad_rowblock_unit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(UnitIO), C.c_void_p]
     lib.iefvad_rowblock_unit.restype = C.c_int
+    i32, vp = C.c_int32, C.c_void_p
+    lib.iefvad_similarity_adj_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.iefvad_similarity_adj_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_similarity_adj.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.iefvad_similarity_adj.restype = C.c_int
+    lib.iefvad_distance_adj.argtypes = [i32, i32, vp, vp]
+    lib.iefvad_distance_adj.restype = C.c_int
+    lib.iefvad_gcn_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.iefvad_gcn_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_gcn_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.iefvad_gcn_forward.restype = C.c_int
+    lib.iefvad_gat_workspace_bytes.argtypes = [i32, i32]
+    lib.iefvad_gat_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_gat_forward.argtypes = [vp, vp, vp, vp, C.c_float, i32, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.iefvad_gat_forward.restype = C.c_int
+    lib.iefvad_resblock_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.iefvad_resblock_workspace_bytes.restype = C.c_size_t
+    lib.iefvad_resblock_forward.argtypes = [vp, C.POINTER(ResblockWeights), vp, vp, i32, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    lib.iefvad_resblock_forward.restype = C.c_int
     lib.iefvad_gemm_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.iefvad_gemm_bias.restype = C.c_int

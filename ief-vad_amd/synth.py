@@ -187,3 +187,24 @@ def make_dropout_mask(seed: int, L: int, B: int, p: float = 0.1, H: int = 8, T: 
     `iefvad_amd.MMFMIL.dropout_mask`."""
     rng = np.random.default_rng([seed, 4242])
     return (rng.random((2, L, B, H, T, T), dtype=np.float32) >= p).astype(np.uint8)
+
+
+# ---- SURVEY 8 rows a12 / a13: seeded inputs and parameters for the module-level fixtures of layers.py / module.py --------------------
+def perturb_module(module, seed: int, scale: float = 0.03):
+    """Add seeded noise to every parameter in registration order.  The reference's default initialisers leave attention / Linear
+    biases at zero and LayerNorm at (1, 0), which would hide a swapped bias or affine term; the fixture generator and the tests call
+    this on the reference class and on its mirror after constructing both under the same torch.manual_seed."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in module.named_parameters():
+            p.add_(torch.randn(p.shape, generator=g, dtype=torch.float32).to(p.device) * scale)
+    return module
+
+
+def smooth_features(seed: int, B: int, T: int = 256, D: int = 768) -> np.ndarray:
+    """[B, T, D] features with temporal structure (a slow random walk plus noise): neighbouring snippets have cosine similarity well
+    above SimilarityAdj's 0.7 threshold, distant ones below it, as consecutive CLIP embeddings of a video do."""
+    rng = np.random.default_rng([seed, 31])
+    walk = np.cumsum(rng.standard_normal((B, T, D)) * 0.25, axis=1)
+    x = walk + rng.standard_normal((B, T, D)) * 0.35 + rng.standard_normal((B, 1, D)) * 0.5
+    return x.astype(np.float32)

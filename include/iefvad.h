@@ -336,6 +336,51 @@ size_t iefvad_auc_ap_workspace_bytes(int64_t n);
 int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int64_t n, int32_t repeat, double* auc, double* ap,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the VadCLIP-residue modules the north star names (SURVEY.md 8 rows a12 / a13 = f-5) ------------------------------------------
+ * /root/reference/model/layers.py and /root/reference/model/module.py are dead code upstream (nothing imports them, a checkpoint holds
+ * no key of theirs), so they are exposed at MODULE level: one entry per class, fp32, on the library's MFMA GEMM + LayerNorm kernels
+ * (csrc/vadclip.h).  All tensors are DEVICE fp32, row-major, 16-byte aligned; every entry takes a caller-owned workspace of
+ * iefvad_*_workspace_bytes(...) bytes and enqueues on `stream`.  The products run on 128 x (128 | 96) x 16 tiles: T (and N for the
+ * GAT layer) must be a multiple of 128, feature widths multiples of 128 (or 96) and of 16.
+ *
+ * iefvad_similarity_adj  layers.py:114-163  x [B,T,d_in], weight0 [d_in,d_out] (weight1 is never read upstream, :132-133),
+ *                        seq_len int32 [B] on the device or NULL -> adj [B,T,T]: cosine similarity of x W0 rows, F.threshold(0.7, 0),
+ *                        row softmax (over [:len, :len] when seq_len is given; zero outside)
+ * iefvad_distance_adj    layers.py:166-179  adj[b,i,j] = exp(-|i - j| / e)
+ * iefvad_gcn_forward     layers.py:64-111   out = adj (x W) (+ bias) + residual.  weight [d_in,d_out]; residual 0 none, 1 identity (d_in ==
+ *                        d_out), 2 Conv1d(d_in, d_out, kernel_size=5, padding=2) over time with conv_w [d_out,d_in,5], conv_b [d_out];
+ *                        act 1 applies QuickGELU to the result (what VadCLIP's caller did), 0 leaves it
+ * iefvad_gat_forward     layers.py:12-49    input [N,f_in], adj [N,N], W [f_in,f_out], a [2 f_out]; alpha = LeakyReLU slope;
+ *                        concat != 0 applies ELU; eval semantics (dropout inactive)
+ * iefvad_resblock_forward module.py:20-43   x, out [T,B,768] sequence-first; attn_mask [T,T] additive fp32 or NULL; key_padding_mask
+ *                        [B,T] bytes (non-zero = padding) or NULL; n_head with 768 / n_head in {96, 128} */
+typedef struct iefvad_resblock_weights {
+    const float* in_proj_w;   /* attn.in_proj_weight [2304,768] */
+    const float* in_proj_b;   /* [2304] */
+    const float* out_proj_w;  /* attn.out_proj.weight [768,768] */
+    const float* out_proj_b;
+    const float* ln_1_w; const float* ln_1_b;
+    const float* ln_2_w; const float* ln_2_b;
+    const float* c_fc_w;      /* mlp.c_fc.weight [3072,768] */
+    const float* c_fc_b;
+    const float* c_proj_w;    /* mlp.c_proj.weight [768,3072] */
+    const float* c_proj_b;
+} iefvad_resblock_weights;
+size_t iefvad_similarity_adj_workspace_bytes(int32_t B, int32_t T, int32_t d_out);
+int iefvad_similarity_adj(const float* x, const float* weight0, const int32_t* seq_len, int32_t B, int32_t T, int32_t d_in, int32_t d_out,
+                          float* adj, void* workspace, size_t workspace_bytes, void* stream);
+int iefvad_distance_adj(int32_t B, int32_t T, float* adj, void* stream);
+size_t iefvad_gcn_workspace_bytes(int32_t B, int32_t T, int32_t d_in, int32_t d_out, int32_t residual);
+int iefvad_gcn_forward(const float* x, const float* adj, const float* weight, const float* bias, const float* conv_w, const float* conv_b,
+                       int32_t residual, int32_t act, int32_t B, int32_t T, int32_t d_in, int32_t d_out, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+size_t iefvad_gat_workspace_bytes(int32_t N, int32_t f_out);
+int iefvad_gat_forward(const float* input, const float* adj, const float* W, const float* a, float alpha, int32_t concat, int32_t N, int32_t f_in,
+                       int32_t f_out, float* out, void* workspace, size_t workspace_bytes, void* stream);
+size_t iefvad_resblock_workspace_bytes(int32_t T, int32_t B, int32_t n_head);
+int iefvad_resblock_forward(const float* x, const iefvad_resblock_weights* w, const float* attn_mask, const uint8_t* key_padding_mask, int32_t T,
+                            int32_t B, int32_t d_model, int32_t n_head, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- unit entry for the bf16 mode's row-block kernels (per-kernel parity tests) -----------------------------------------
  * Launches ONE production kernel of compute = IEFVAD_COMPUTE_BF16 -- the symbol, grid and LDS size iefvad_forward uses at that row
  * count (the persistent variants from two 64-row blocks per workgroup on) -- on caller-supplied DEVICE rows, with the handle's

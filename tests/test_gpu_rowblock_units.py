@@ -69,14 +69,15 @@ def run(model, stage, layer, rows, **ptrs):
 
 def check_bf16_output(got: torch.Tensor, ref64: torch.Tensor, tol: float, what: str):
     """`got` (bf16 from the kernel) against the fp64 value: equal to bf16(ref) wherever ref is further than `tol` from a rounding
-    boundary; on a boundary either neighbour.  Returns the fraction of boundary elements."""
+    boundary; on a boundary either neighbour.  Returns the fraction of boundary elements (values large enough that one bf16 step
+    exceeds 2 tol; smaller ones are trivially "on a boundary" and do not count)."""
     g = got.to(torch.float64).cpu()
     lo, hi = bf(ref64 - tol), bf(ref64 + tol)
     fragile = lo != hi
     exact = bf(ref64)
     assert torch.equal(g[~fragile], exact[~fragile]), (what, float((g - exact)[~fragile].abs().max()))
-    assert bool(((g == lo) | (g == hi))[fragile].all()), what
-    frac = float(fragile.double().mean())
+    assert bool(((g >= lo) & (g <= hi))[fragile].all()), what        # one of the two neighbours (for tiny values, whose bf16 step is below `tol`, anything between)
+    frac = float((fragile & (bf_ulp(ref64) > 2 * tol)).double().mean())
     assert frac < 0.02, (what, frac)
     return frac
 

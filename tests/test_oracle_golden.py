@@ -118,3 +118,69 @@ def test_loss_gradient_fixture_is_consistent_with_the_loss_fixture(golden_dir):
         assert abs(float(grads[f"seed{seed}_total"]) - want) <= 1e-6 * max(1.0, abs(want))      # fp32 terms there, fp64 here
         assert np.isfinite(grads[f"seed{seed}_logits_video_sums"]).all()
         assert np.abs(grads[f"seed{seed}_image_mu_zero_row"]).max() > 1e12          # the clamp branch of F.normalize
+
+
+# ---- the VadCLIP-residue classes, oracle restatement vs the reference's own outputs ---------------------------
+def _vadclip_setup(golden_dir):
+    """The fixture's modules rebuilt from the product's mirrors (same seed -> same init -> same perturbation): their state_dicts feed
+    the oracle.  Returns (fixture, inputs, state_dicts)."""
+    import os
+    import torch
+    from iefvad_amd import layers as PL, module as PM, synth
+    g = np.load(os.path.join(golden_dir, "vadclip_modules.npz"))
+    mods = {}
+    for key, seed, pseed, make in (("sim", 101, 1, lambda: PL.SimilarityAdj(768, 384)),
+                                   ("gc1", 102, 2, lambda: PL.GraphConvolution(768, 384, residual=True)),
+                                   ("gc2", 103, 3, lambda: PL.GraphConvolution(384, 384, bias=True, residual=True)),
+                                   ("gat", 104, 4, lambda: PL.GraphAttentionLayer(768, 128, dropout=0.0, alpha=0.2, concat=True)),
+                                   ("blk", 105, 5, lambda: PM.ResidualAttentionBlock(768, 8, None))):
+        torch.manual_seed(seed)
+        m = synth.perturb_module(make(), pseed).eval()
+        chk = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for _, p in m.named_parameters()])
+        assert chk.shape == g[key + "_checks"].shape and np.allclose(chk, g[key + "_checks"], rtol=1e-12, atol=1e-9), key   # same registration order, same initialisers
+        mods[key] = m
+    x = torch.from_numpy(synth.smooth_features(int(g["x_seed"]), 2))
+    xs = torch.from_numpy(synth.smooth_features(4, 2)).permute(1, 0, 2).contiguous() * 0.3
+    return g, x, xs, mods
+
+
+def test_vadclip_module_oracles_match_the_reference_outputs(golden_dir):
+    """oracle/vadclip_oracle.py against what the reference's own classes computed (tests/golden/make_golden.py::gen_vadclip_cases):
+    SimilarityAdj with and without seq_len, GraphConvolution with the Conv1d and the identity residual, GraphAttentionLayer incl. rows
+    without any edge, ResidualAttentionBlock plain and with attn_mask + key padding mask.  fp32 gates."""
+    import torch
+    from oracle import vadclip_oracle as vo
+    g, x, xs, mods = _vadclip_setup(golden_dir)
+    rows = [int(r) for r in g["rows"]]
+    sd = {k: {n: p.detach() for n, p in m.named_parameters()} for k, m in mods.items()}
+    assert float(g["sim_threshold_margin"]) > 2e-5
+    adj_full = vo.similarity_adj(sd["sim"], x, None)
+    adj_len = vo.similarity_adj(sd["sim"], x, [200, 256])
+    assert np.abs(adj_full[:, rows].numpy() - g["adj_full"]).max() <= 2e-6
+    assert np.abs(adj_len[:, rows].numpy() - g["adj_len"]).max() <= 2e-6
+    assert float(adj_len[0, 200:].abs().max()) == 0 and float(adj_len[0, :, 200:].abs().max()) == 0
+    y1 = vo.graph_convolution(sd["gc1"], x, adj_len)
+    assert np.abs(y1[:, rows].numpy() - g["gc1_out"]).max() <= 2e-5
+    x1 = vo.quick_gelu(y1)
+    assert np.abs(x1[:, rows].numpy() - g["gc1_gelu"]).max() <= 2e-5
+    y2 = vo.graph_convolution(sd["gc2"], x1, adj_len)
+    assert np.abs(y2[:, rows].numpy() - g["gc2_out"]).max() <= 2e-5
+    gen = torch.Generator().manual_seed(9)
+    gadj = (torch.rand(256, 256, generator=gen) < 0.1).float() * torch.rand(256, 256, generator=gen)
+    gadj[[5, 77, 255]] = 0
+    got = vo.graph_attention(sd["gat"], x[0], gadj, 0.2, True)
+    assert np.abs(got[rows + [5, 77]].numpy() - g["gat_out"]).max() <= 2e-5
+    yb = vo.residual_attention_block(sd["blk"], xs, 8)
+    assert np.abs(yb[rows].numpy() - g["blk_out"]).max() <= 2e-5
+    mask = torch.full((256, 256), float("-inf"))
+    for c in range(4):
+        mask[c * 64:(c + 1) * 64, c * 64:(c + 1) * 64] = 0
+    pad = torch.zeros(2, 256, dtype=torch.bool)
+    pad[1, 216:] = True
+    ym = vo.residual_attention_block(sd["blk"], xs, 8, mask, pad)
+    assert np.abs(ym[rows].numpy() - g["blk_masked_out"]).max() <= 2e-5
+    # DistanceAdj: parity unpinned (layers.py:176,178 need 'cuda'); the restated formula against scipy's pdist, as the source computes it
+    from scipy.spatial.distance import pdist, squareform
+    d = squareform(pdist(np.arange(256).reshape(-1, 1), metric="cityblock").astype(np.float32))
+    want = np.exp(-d / np.exp(np.float32(1.0)))
+    assert np.abs(vo.distance_adj(2, 256).numpy() - want[None]).max() <= 1e-6
