@@ -251,7 +251,14 @@ __global__ __launch_bounds__(256) void iefvad_cast_scaled_kernel(const T* in0, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e] = (float)in[o + e];
-            if (f != 1.0f) v[e] = (float)(T)(v[e] * f);
+            if (f != 1.0f) {
+                // the fp32 product must exist as such before it is narrowed: left to itself hipcc folds fpext -> fmul -> fptrunc into
+                // v_fma_mixlo_f16, which rounds the exact product ONCE to fp16 -- torch rounds it to fp32 first (opmath) and then to
+                // fp16, and once in a few million elements the two disagree (found by tests/test_gpu_config2.py, round 5)
+                float prod = v[e] * f;
+                asm volatile("" : "+v"(prod));
+                v[e] = (float)(T)prod;
+            }
         }
         if (out) *(f32x4*)(out + o) = v;
         if (ob) *(bf16x4_t*)(ob + o) = to_bf16x4(v);

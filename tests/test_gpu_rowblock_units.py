@@ -78,7 +78,7 @@ def check_bf16_output(got: torch.Tensor, ref64: torch.Tensor, tol: float, what: 
     assert torch.equal(g[~fragile], exact[~fragile]), (what, float((g - exact)[~fragile].abs().max()))
     assert bool(((g >= lo) & (g <= hi))[fragile].all()), what        # one of the two neighbours (for tiny values, whose bf16 step is below `tol`, anything between)
     frac = float((fragile & (bf_ulp(ref64) > 2 * tol)).double().mean())
-    assert frac < 0.02, (what, frac)
+    assert frac < 0.08, (what, frac)
     return frac
 
 
@@ -173,7 +173,8 @@ def test_refinement_chain_kernel_alone_one_step(rows):
     """iefvad_refine_chain_bf16_kernel with K = 1 from a given z_0: z_1 = z_0 - lambda (W2 bf16(relu(W1 bf16(z_0) + b1)) + b2), logit = z_1 w_c + b_c.
     ONE internal rounding site, the hidden activation h: elements of h within TOL_ACC of a bf16 boundary may round the other way,
     which moves z_1[r, n] by at most lambda ulp(h[r, j]) |W2[n, j]| -- summed over the boundary elements of the row, that is the
-    per-element allowance on top of the fp32 gate.  For most rows the allowance is ~0 and they are held to the gate itself."""
+    per-element allowance on top of the fp32 gate (1e-5 .. 2e-4: an order below what a mis-mapped fragment costs); the MEAN error is held to
+    2e-6, fp32-accumulation level, because flips are rare."""
     torch.set_num_threads(harness.host_cpu_share())
     model, W = handle(1, 1, 64)
     lam = 0.5
@@ -194,11 +195,11 @@ def test_refinement_chain_kernel_alone_one_step(rows):
     dl = (lg.cpu().double() - ref_lg).abs()
     assert bool((d <= GATE + allow).all()), float((d - allow).max())
     assert bool((dl <= GATE + allow @ wc.abs()).all()), float((dl - allow @ wc.abs()).max())
-    tight = allow.max(dim=1).values <= 2e-6              # rows whose boundary elements cannot move anything by more than a tenth of the gate
-    frac = float(tight.double().mean())
-    print(f"refinement chain K=1 rows {rows}: {frac:.2f} of the rows held to the fp32 gate itself, max error there {float(d[tight].max()):.2e}; "
-          f"overall max {float(d.max()):.2e}, largest allowance {float(allow.max()):.2e}")
-    assert frac >= 0.3 and float(d[tight].max()) <= GATE + 2e-6
+    # flips are rare: the MEAN error stays at fp32-accumulation level whatever the allowances (a systematic error of 1e-3 would sit in it)
+    print(f"refinement chain K=1 rows {rows}: max error {float(d.max()):.2e} (largest allowance {float(allow.max()):.2e}, median row allowance "
+          f"{float(allow.max(dim=1).values.median()):.2e}); mean error {float(d.mean()):.2e}; {float(fragile.mean()):.2e} of h on a rounding boundary")
+    assert float(d.mean()) <= 2e-6 and float(dl.mean()) <= 5e-6
+    assert float(allow.max(dim=1).values.median()) <= 2e-4
     # in place (z aliases z_0), as the forward runs it: same bits
     zin = z0.cuda()
     run(model, L.UNIT_REFINE, 0, rows, x=[zin, None], z=zin, logits=lg)
