@@ -472,22 +472,56 @@ def train_step_one(dev, a, compute, chunks=128, steps=4):
     labels[chunks // 2:, 3] = 1
     lengths = torch.full((chunks,), T, dtype=torch.int64, device=dev)
     for _ in range(2):
-        terms = trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0)
+        trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0, want_terms=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        terms = trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0)
+    for s_ in range(steps):      # the loss terms are formed only on the step that is logged (ucf_train.py:108-128 prints every print_steps samples)
+        terms = trainer.train_step(model, opt, img, ev, labels, lengths, "StudentT", 1.0, 1.0, want_terms=(s_ == steps - 1))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flops = 3 * TOTAL_FLOPS_PER_SNIPPET * chunks * T
-    return {"workload": f"training step, {chunks} chunks x {T} x {D} (ucf_train.py: 2 x batch_size 64), K={K_STEPS}, L={L}, StudentT, attention "
-                        f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute={compute}",
-            "snippets_per_s": chunks * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_tflop_per_step": flops / 1e12,
-            "achieved_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "peak_note": ("the fp32 MFMA peak is the yardstick of an fp32-accurate step; in bf16x6 every projection product (forward, dX, dW) runs "
-                          "as six bf16 MFMA products on the bf16 pipe, so the ratio can exceed 1") if compute == "bf16x6" else
-                         "every product on the fp32 MFMA instruction",
-            "loss_total": float(terms["total"])}
+    # the pipe the step's projection products issue on: bf16 MFMA (six products per algorithmic multiply-add) in bf16x6, fp32 MFMA in f32
+    split = compute == "bf16x6"
+    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    out = {"workload": f"training step, {chunks} chunks x {T} x {D} (ucf_train.py: 2 x batch_size 64), K={K_STEPS}, L={L}, StudentT, attention "
+                       f"dropout 0.1 (library mask generator), AdamW lr 2e-5, compute={compute}",
+           "snippets_per_s": chunks * T / dt, "ms_per_step": dt * 1e3, "steps": steps, "algorithmic_tflop_per_step": flops / 1e12,
+           "achieved_tflops": flops / dt / 1e12, "peak_tflops": peak, "frac": flops / dt / 1e12 / peak,
+           "mfma_pipe_util": flops / dt / 1e12 * (PRODUCTS_PER_MAC[compute]) / peak,
+           "peak_note": ("whole-step algorithmic FLOPs (3 x the forward's) over wall time against the dense bf16 MFMA peak; mfma_pipe_util counts the six "
+                         "executed bf16 products per multiply-add of the projection products (the attention products of the step run on the fp32 "
+                         "MFMA instruction and the row kernels on none, so this is an upper bound on the pipe's real occupancy)") if split else
+                        "whole-step algorithmic FLOPs over wall time against the fp32 MFMA peak: every product on v_mfma_f32_32x32x2_f32",
+           "loss_total": float(terms["total"])}
+    return out
+
+
+def metric_tail_block(dev, n=8192 * T, sample=131072):
+    """the metric tail of test() (/root/reference/test.py:158-159: sklearn on np.repeat(scores, 16)) as the library entry
+    iefvad_auc_ap on config 4's 2,097,152 snippet scores (33.5 M frames), device time incl. the result read-back; beside it sklearn on
+    the host for a bounded sample of the same vectors (its cost grows n log n), and the agreement of the two on that sample."""
+    import numpy as np
+    import torch
+    from iefvad_amd import harness, synth
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    gen = torch.Generator(device=dev).manual_seed(5)
+    scores = torch.sigmoid(torch.randn(n, device=dev, generator=gen) * 2)
+    gt = torch.from_numpy(synth.make_gt(5, n)).to(torch.uint8).to(dev)
+    harness.device_auc_ap(scores, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        auc, ap = harness.device_auc_ap(scores, gt)
+    dt = (time.perf_counter() - t0) / reps
+    s_h, g_h = scores[:sample].cpu().numpy(), gt[: 16 * sample].cpu().numpy()
+    t0 = time.perf_counter()
+    a0, p0 = roc_auc_score(g_h, np.repeat(s_h, 16)), average_precision_score(g_h, np.repeat(s_h, 16))
+    t_sk = time.perf_counter() - t0
+    a1, p1 = harness.device_auc_ap(scores[:sample], gt[: 16 * sample])
+    return {"snippets": n, "frames": 16 * n, "device_ms": dt * 1e3, "auc": auc, "ap": ap,
+            "sklearn_sample": {"snippets": sample, "host_ms": t_sk * 1e3, "abs_auc_diff": abs(a1 - a0), "abs_ap_diff": abs(p1 - p0)},
+            "kernel": "iefvad_auc_ap: radix sort of (score, positives) pairs + scan + tie-group reduction (csrc/metrics.h)"}
 
 
 def xd_parts():
@@ -694,6 +728,7 @@ def main():
             line["shang_msad_eval"] = dataset_eval("BASELINE config 5 (real gt and label order, synthetic features)", config5_parts(),
                                                    19, 5, "bf16", dev, a, batch_chunks=128, lanes=2)
             line["train_step"] = train_step_block(dev, a)
+            line["metric_tail"] = metric_tail_block(dev)
         if gpu and world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, a.cpu_seconds)
         print(json.dumps(line), file=json_out, flush=True)

@@ -62,3 +62,8 @@ def test_default_line_structure_and_consistency():
     for m in (t, t["f32_mode"]):
         assert m["snippets_per_s"] > 0 and abs(m["snippets_per_s"] - 128 * 256 / (m["ms_per_step"] * 1e-3)) < 1e-6 * m["snippets_per_s"]
         assert math.isfinite(m["loss_total"])
+        assert 0 < m["frac"] < 1 and abs(m["frac"] - m["achieved_tflops"] / m["peak_tflops"]) < 1e-9 and 0 < m["mfma_pipe_util"] <= 1
+    assert t["peak_tflops"] == 2500.0 and t["f32_mode"]["peak_tflops"] == 157.3           # each mode against the pipe it issues on
+    mt = d["metric_tail"]                                                                # iefvad_auc_ap on config 4's 2.1 M scores
+    assert mt["snippets"] == 8192 * 256 and mt["device_ms"] > 0 and 0 < mt["auc"] < 1 and 0 < mt["ap"] < 1
+    assert mt["sklearn_sample"]["abs_auc_diff"] < 1e-12 and mt["sklearn_sample"]["abs_ap_diff"] < 1e-12

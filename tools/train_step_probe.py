@@ -78,7 +78,7 @@ def main():
                                   f"attention dropout {a.dropout}, AdamW lr 2e-5, compute={a.compute}",
                       "ms_per_step": dt * 1e3, "snippets_per_s": snips / dt, "forward_plus_loss_ms": fwd, "backward_plus_adamw_ms": bwd,
                       "algorithmic_tflop_per_step": step_flops / 1e12, "achieved_tflops": step_flops / dt / 1e12,
-                      "frac_of_fp32_mfma_peak": step_flops / dt / 1e12 / 157.3, "loss": float(total.detach()),
+                      "frac_of_bf16_mfma_peak": step_flops / dt / 1e12 / 2500.0, "loss": float(total.detach()),
                       "train_buffer_gib": model._handle and iefvad_amd.lib.load_library().iefvad_train_workspace_bytes(model._handle, B) / 2**30}))
 
 
