@@ -3,7 +3,7 @@
 # Writes everything under gpurun_out/<round>/; the summaries worth keeping are copied to profiles/<round>_* afterwards
 # (tools/keep_profiles.sh).  `head` = the commit the box's snapshot was taken from (there is no .git on the box).
 set -u
-RND="${1:-r04}"
+RND="${1:-r05}"
 HEAD="${2:-unknown}"
 export IEFVAD_HEAD="$HEAD"
 R="$PWD"
@@ -86,6 +86,9 @@ for pz in 1 0; do
 import json,sys
 d=json.loads(sys.stdin.read()); print('IEFVAD_PERSIST=$pz', round(d['value']), 'snippets/s', round(d['ms_per_step'],2), 'ms/step', {k:round(v,2) for k,v in d['stage_ms_per_step'].items()})" >> "$O/persist_ab.log"
 done
+echo "[11] metric tail (iefvad_auc_ap at config 4's size): kernel stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_metric" -o t -- python3 "$R/tools/metric_probe.py" > "$O/metric_tail.log" 2> "$O/trace_metric.log"
+python3 "$R/tools/summarize_profile.py" "$(find "$O/trace_metric" -name '*kernel_stats.csv' | head -1)" "$O/metric_tail_kernel_stats.csv" > /dev/null
 # keep the merge-back small: the raw traces are large
 find "$O" -name '*kernel_trace.csv' -size +8M -delete
 find "$O" -name '*.db' -delete

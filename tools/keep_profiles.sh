@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of a collect_profiles.sh run (gpurun_out/<round>/) into profiles/<round>_* (tracked).
 set -eu
-RND="${1:-r04}"
+RND="${1:-r05}"
 O=gpurun_out/$RND
 cp $O/bench_default.json profiles/${RND}_bench_default.json.log
 for m in bf16x6 bf16 f32; do
@@ -26,4 +26,6 @@ cp $O/train_step_kernel_stats.csv profiles/${RND}_train_step_kernel_stats.csv
 cp $O/host_list_probe.log profiles/${RND}_host_list_probe.log
 [ -f $O/outproj_pchain_phase_stamps.log ] && cp $O/outproj_pchain_phase_stamps.log profiles/${RND}_outproj_pchain_phase_stamps.log
 cp $O/persist_ab.log profiles/${RND}_persistent_rowblock_ab.log
+[ -f $O/metric_tail.log ] && cp $O/metric_tail.log profiles/${RND}_metric_tail.log
+[ -f $O/metric_tail_kernel_stats.csv ] && cp $O/metric_tail_kernel_stats.csv profiles/${RND}_metric_tail_kernel_stats.csv
 echo kept
