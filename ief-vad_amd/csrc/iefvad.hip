@@ -28,6 +28,7 @@
 #include "refine_chain_bf16.h"
 #include "outproj_ln_chain_bf16.h"
 #include "outproj_ln_pchain_bf16.h"
+#include "outproj_ln_rchain_bf16.h"
 #include "inproj_chain_bf16.h"
 #include "heads_chain_bf16.h"
 #include "heads_pchain_bf16.h"
@@ -74,6 +75,7 @@ struct iefvad_handle {
     int rowblock_min_wgs;  // bf16 mode: the row-block kernels take a projection from this many workgroups on (IEFVAD_ROWBLOCK_MIN_WGS overrides)
     bool no_inproj_chain;
     char* oproj_stream[2][IEFVAD_MAX_LAYERS];   // bf16 mode: out_proj weights in per-wave fragment order (outproj_ln_chain_bf16.h)
+    char* oproj_stream_r[2][IEFVAD_MAX_LAYERS]; // the same matrices with the output columns dealt to the waves for the in-register LayerNorm (outproj_ln_rchain_bf16.h)
     bool dense_encoder;    // IEFVAD_DENSE_ENCODER=1: whole-video passes run the encoder on whole 256-row chunks (pad rows computed), the tail on the gathered valid rows
     bool no_chain;
     char* chain_stream;    // bf16 mode: the refinement weights in the chain kernel's per-wave piece order (refine_chain_bf16.h)
@@ -207,6 +209,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OP_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_rchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OR_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_heads_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HP_LDS_BYTES);
     if (e == hipSuccess)
@@ -271,6 +276,7 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
     for (int m = 0; m < 2; ++m)
         for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) {
             if (h->oproj_stream[m][l]) (void)hipFree(h->oproj_stream[m][l]);
+            if (h->oproj_stream_r[m][l]) (void)hipFree(h->oproj_stream_r[m][l]);
             if (h->iproj_stream[m][l]) (void)hipFree(h->iproj_stream[m][l]);
         }
     if (h->arena_s) (void)hipFree(h->arena_s);
@@ -443,6 +449,9 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
             for (int l = 0; l < L; ++l) {
                 if (!h->oproj_stream[m][l]) HIP_TRY(hipMalloc((void**)&h->oproj_stream[m][l], wstream_bytes()));
                 hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(256), dim3(256), 0, stream, h->out_wb[m][l], h->oproj_stream[m][l], 1);
+                HIP_TRY(hipGetLastError());
+                if (!h->oproj_stream_r[m][l]) HIP_TRY(hipMalloc((void**)&h->oproj_stream_r[m][l], wstream_bytes()));
+                hipLaunchKernelGGL(iefvad_wstream_pack_colmap_kernel, dim3(256), dim3(256), 0, stream, h->out_wb[m][l], h->oproj_stream_r[m][l]);
                 HIP_TRY(hipGetLastError());
                 if (!h->iproj_stream[m][l]) HIP_TRY(hipMalloc((void**)&h->iproj_stream[m][l], wstream_bytes(IC_NPASS)));
                 hipLaunchKernelGGL(iefvad_wstream_pack_kernel, dim3(512), dim3(256), 0, stream, h->in_wb[m][l], h->iproj_stream[m][l], IC_NPASS);
@@ -804,12 +813,20 @@ static int launch_outproj_ln_chain(iefvad_handle* h, int l, bool whiten, const b
 #ifdef OC_DIAG
     { static unsigned long long* dg = [] { const char* v = getenv("IEFVAD_OC_DIAG_PTR"); return v ? (unsigned long long*)strtoull(v, nullptr, 0) : nullptr; }(); oa.diag = dg; }
 #endif
-    // from two blocks per workgroup on: the persistent kernel, one workgroup per CU, the next block's image fetched during the
-    // LayerNorm epilogue (outproj_ln_pchain_bf16.h; same bits); IEFVAD_PERSIST=0 keeps the one-block-per-workgroup kernels (A/B)
+    // From two blocks per workgroup on: the persistent kernel, one workgroup per CU, the next block's image fetched during the LayerNorm
+    // epilogue (outproj_ln_pchain_bf16.h; same bits); IEFVAD_PERSIST=0 keeps the one-block-per-workgroup kernels (A/B).
+    // IEFVAD_OUTLN=r (opt-in, round 5's experiment): the LayerNorm in the accumulator registers (outproj_ln_rchain_bf16.h: its own weight
+    // streams, any number of blocks per workgroup; bit-identical; epilogue 30 k -> 13 k cycles per block, but its 32 - 64-byte row pieces
+    // cost more in memory waits than the park-through-LDS epilogue costs in barriers: 19.8 vs 16.7 ms per step, TRIED.md)
+    static const bool rchain = [] { const char* v = getenv("IEFVAD_OUTLN"); return v && v[0] == 'r'; }();
     static const bool persist = [] { const char* v = getenv("IEFVAD_PERSIST"); return !(v && v[0] == '0'); }();
     const int gx = h->num_cus / 2;
+    const int nblk = rows / OC_BM;
     hipEvent_t e = tm.begin(ST_OUT);
-    if (persist && rows / OC_BM >= 2 * gx)
+    if (rchain && persist) {
+        for (int m = 0; m < 2; ++m) oa.p[m].stream = h->oproj_stream_r[m][l];
+        hipLaunchKernelGGL(iefvad_outproj_ln_rchain_bf16_kernel, dim3(nblk < gx ? nblk : gx, 2), dim3(512), OR_LDS_BYTES, stream, oa);
+    } else if (persist && nblk >= 2 * gx)
         hipLaunchKernelGGL(iefvad_outproj_ln_pchain_bf16_kernel, dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
     else
         hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);

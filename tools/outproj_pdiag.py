@@ -23,13 +23,19 @@ with torch.no_grad():
         m(x, y, None, None, None)
 torch.cuda.synchronize()
 d = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)     # the LAST out_proj launch of the forward (layer 1: with whitening)
-nb = d[:, 5]
-names = ["top of block -> image ready (wait + barrier)", "main loop (24 k-steps x 24 MFMAs) + ring drain", "image-free barrier + next image DMA issue",
-         "4 x (park + barrier) + 4 x end barrier", "4 x (LayerNorm(s) of 2 rows per wave + stores)"]
+if os.environ.get("IEFVAD_OUTLN", "p")[0] == "p":      # round 4's kernel (outproj_ln_pchain_bf16.h)
+    nb = d[:, 5]
+    names = ["top of block -> image ready (wait + barrier)", "main loop (24 k-steps x 24 MFMAs) + ring drain", "image-free barrier + next image DMA issue",
+             "4 x (park + barrier) + 4 x end barrier", "4 x (LayerNorm(s) of 2 rows per wave + stores)"]
+else:                                                   # round 5's (outproj_ln_rchain_bf16.h: LayerNorm in the accumulator registers)
+    nb = d[:, 6]
+    names = ["top of block -> image ready (wait + barrier)", "main loop (24 k-steps x 24 MFMAs) + ring drain",
+             "bias + residual of row group 0, requests of groups 1 - 3, image-free barrier, next image DMA issue", "wait for the residual rows, bias + residual of groups 1 - 3",
+             "LayerNorm(s) in the accumulator layout (2 exchanges each)", "stores (fp32 / bf16 pieces)"]
 print(f"{d.shape[0]} workgroups, {nb.mean():.1f} blocks each; s_memtime ticks (100 MHz) per BLOCK: median / p10 / p90")
 tot = 0
 for i, n in enumerate(names):
     v = d[:, i] / nb
     tot += np.median(v)
-    print(f"  {n:56s} {np.median(v):9.1f} {np.percentile(v, 10):9.1f} {np.percentile(v, 90):9.1f}")
-print(f"  {'sum':56s} {tot:9.1f}")
+    print(f"  {n:100s} {np.median(v):9.1f} {np.percentile(v, 10):9.1f} {np.percentile(v, 90):9.1f}")
+print(f"  {'sum':100s} {tot:9.1f}")
