@@ -155,6 +155,14 @@ def test_row_scale_in_the_input_load_equals_scaling_the_tensor(compute, dtype):
         assert torch.equal(got[k], want[k]), k
         assert torch.equal(got_e[k], want_e[k]), k
     assert not torch.equal(got["logits"], clean["logits"])
+    # the scale vector is indexed by the row's position in the CALL: three internal passes of four, four and one chunk see their own slices
+    small = gpu_model(synth.make_state_dict(5), outputs="scores", compute=compute, micro_batch=4)
+    with torch.no_grad():
+        got_mb = small(img, ev, None, None, None, row_scale=(sc, sc))
+        both = scaled.clone()
+        want_mb = small(both, scaled_e, None, None, None)
+    for k in want_mb:
+        assert torch.equal(got_mb[k], want_mb[k]), k
     with pytest.raises(ValueError, match="row_scale"):
         model(img, ev, None, None, None, row_scale=(sc[:-1], None))
 
