@@ -56,7 +56,7 @@ GEMM_FLOPS_PER_SNIPPET = 4 * (2 * D * 3 * D) + 4 * (2 * D * D) + 4 * (2 * D * D)
 TOTAL_FLOPS_PER_SNIPPET = 26_740_224 + K_STEPS * 2_359_296
 PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, chip-level table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                  # dense bf16 / fp16 MFMA (same table)
-PROFILE_ROUNDS = ("r04", "r03")                                 # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in, newest first
+PROFILE_ROUNDS = ("r05", "r04")                                # profiles/<round>_*_hbm_traffic.json this build's kernels were measured in, newest first
 GEMM_KERNEL = {"f32": "iefvad_gemm_f32_t256_kernel",
                "bf16": "iefvad_inproj_chain_f32in_kernel / iefvad_inproj_chain_bf16_kernel (in_proj; the first layer rounds the fp32 "
                        "rows to bf16 itself) + iefvad_refine_chain_bf16_kernel (the 2K refinement projections + scorer, one launch) + "

@@ -1919,7 +1919,9 @@ static size_t metric_layout(int64_t n, char* base, MetricWs* w) {
     char* bstart = take(tiles * 4);
     char* ap_part = take(tiles * 8);
     char* tail = take(16);
+    char* dtotal = take(MT_RADIX * 4);
     if (w) {
+        w->dtotal = (unsigned*)dtotal;
         w->a = (unsigned long long*)a; w->b = (unsigned long long*)b; w->hist = (unsigned*)hist; w->bsum = (unsigned*)bsum;
         w->bstart = (unsigned*)bstart; w->ap_part = (double*)ap_part; w->auc_num = (unsigned long long*)tail; w->flags = (unsigned*)(tail + 8);
     }
@@ -1951,8 +1953,8 @@ extern "C" int iefvad_auc_ap(const float* scores, const uint8_t* gt_frames, int6
     for (int pass = 0; pass < 4; ++pass) {          // the key is the upper word of a pair
         const int shift = 32 + 8 * pass;
         hipLaunchKernelGGL(iefvad_metric_hist_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, (long long)n, shift, w.hist, tiles);
-        hipLaunchKernelGGL(iefvad_metric_scan_kernel, dim3(1), dim3(1024), 0, stream, w.hist, (long long)tiles * MT_RADIX);
-        hipLaunchKernelGGL(iefvad_metric_scatter_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, dst, (long long)n, shift, w.hist, tiles);
+        hipLaunchKernelGGL(iefvad_metric_digit_scan_kernel, dim3(MT_RADIX), dim3(256), 0, stream, w.hist, tiles, w.dtotal);
+        hipLaunchKernelGGL(iefvad_metric_scatter_kernel, dim3(tiles), dim3(MT_THREADS), 0, stream, src, dst, (long long)n, shift, w.hist, tiles, w.dtotal);
         unsigned long long* t = src; src = dst; dst = t;
     }
     // four passes: the sorted pairs are back in w.a, w.b is free for the two scanned columns

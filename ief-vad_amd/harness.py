@@ -175,7 +175,9 @@ def device_auc_ap(scores: torch.Tensor, gt: torch.Tensor, repeat: int = 16) -> T
     g = torch.as_tensor(gt).reshape(-1)
     if g.numel() != s.numel() * repeat:
         raise ValueError("gt must hold `repeat` frames per snippet")
-    g = (g != 0).to(torch.uint8).to(s.device, non_blocking=True).contiguous()
+    # the kernel counts every non-zero byte as an anomalous frame: one-byte ground truth (uint8 / bool) goes in as it is
+    g = g if g.dtype in (torch.uint8, torch.bool) else (g != 0).to(torch.uint8)
+    g = g.to(s.device, non_blocking=True).contiguous()
     lib = _lib.load_library()
     n = s.numel()
     with torch.cuda.device(s.device):
