@@ -1904,6 +1904,26 @@ extern "C" int iefvad_adamw_step(float* param, const float* grad, float* exp_avg
     return 0;
 }
 
+extern "C" int iefvad_adamw_step_multi(const iefvad_adamw_tensor* table_dev, int32_t count, uint64_t total_chunks, double lr, double beta1, double beta2,
+                                       double eps, double weight_decay, int32_t step, void* stream_) {
+    if (!table_dev) return fail("iefvad_adamw_step_multi: null argument");
+    if (step < 1) return fail("iefvad_adamw_step_multi: step counts from 1 (got %d)", step);
+    if (count <= 0 || total_chunks == 0) return 0;
+    if (total_chunks > 0x7fffffffull) return fail("iefvad_adamw_step_multi: too many chunks");
+    AdamWMultiArgs a;
+    a.table = table_dev; a.count = count;
+    a.decay = (float)(1.0 - lr * weight_decay);       // the scalars of iefvad_adamw_step, formed the same way
+    a.w1 = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.eps = (float)eps;
+    hipLaunchKernelGGL(iefvad_adamw_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // metric tail of the evaluation loop (metrics.h)
 // ------------------------------------------------------------------------------------------------

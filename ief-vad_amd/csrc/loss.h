@@ -280,3 +280,35 @@ __global__ __launch_bounds__(256) void iefvad_adamw_kernel(AdamWArgs a) {
         a.p[i] = p - a.step_size * (m / denom);                                    // addcdiv_(exp_avg, denom, value = -step_size)
     }
 }
+
+// The same update for MANY tensors in one launch (iefvad_adamw_step_multi): the reference's model has 78 parameter tensors, 46 of them
+// 768-element vectors, and one launch each was 0.40 ms of a 30 ms training step for 0.13 ms worth of memory traffic.  `table` is a
+// DEVICE array; a workgroup owns ADAMW_CHUNK consecutive elements of one tensor and finds it by bisection over first_chunk.
+#define ADAMW_CHUNK 4096
+struct AdamWMultiArgs {
+    const iefvad_adamw_tensor* table;
+    int count;
+    float decay, w1, beta2, w2, step_size, bc2_sqrt, eps;
+};
+__global__ __launch_bounds__(256) void iefvad_adamw_multi_kernel(AdamWMultiArgs a) {
+    const unsigned long long chunk = blockIdx.x;
+    int lo = 0, hi = a.count - 1;
+    while (lo < hi) {                                       // the last tensor whose first_chunk <= chunk
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.table[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const iefvad_adamw_tensor t = a.table[lo];
+    const size_t i0 = (size_t)(chunk - t.first_chunk) * ADAMW_CHUNK;
+    const size_t i1 = i0 + ADAMW_CHUNK < t.n ? i0 + ADAMW_CHUNK : (size_t)t.n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float g = t.grad[i];
+        float p = t.param[i];
+        p = p * a.decay;
+        const float m = t.exp_avg[i] + a.w1 * (g - t.exp_avg[i]);
+        const float v = a.beta2 * t.exp_avg_sq[i] + a.w2 * (g * g);
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        t.exp_avg[i] = m;
+        t.exp_avg_sq[i] = v;
+        t.param[i] = p - a.step_size * (m / denom);
+    }
+}

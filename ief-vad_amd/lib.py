@@ -31,7 +31,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled", "iefvad_rowblock_unit",
            "iefvad_similarity_adj", "iefvad_similarity_adj_workspace_bytes", "iefvad_distance_adj", "iefvad_gcn_forward",
            "iefvad_gcn_workspace_bytes", "iefvad_gat_forward", "iefvad_gat_workspace_bytes", "iefvad_resblock_forward",
-           "iefvad_resblock_workspace_bytes"]
+           "iefvad_resblock_workspace_bytes", "iefvad_adamw_step_multi"]
 COMM_ID_BYTES = 128
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -164,6 +164,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_train_backward.restype = C.c_int
     lib.iefvad_adamw_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_double] * 5 + [C.c_int32, C.c_void_p]
     lib.iefvad_adamw_step.restype = C.c_int
+    lib.iefvad_adamw_step_multi.argtypes = [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_double] * 5 + [C.c_int32, C.c_void_p]
+    lib.iefvad_adamw_step_multi.restype = C.c_int
     lib.iefvad_host_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]
     lib.iefvad_host_gather.restype = C.c_int
     lib.iefvad_host_gather_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int64, C.c_int32]

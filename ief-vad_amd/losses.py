@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict
 
+import numpy as np
 import torch
 
 from . import lib as _lib
@@ -137,7 +138,8 @@ def training_loss(outputs: Dict[str, torch.Tensor], labels: torch.Tensor, length
 
 class AdamW(torch.optim.Optimizer):
     """torch.optim.AdamW's update (the optimiser of /root/reference/train/ucf_train.py:28, xd_train.py:25) with the arithmetic in
-    libiefvad: one `iefvad_adamw_step` launch per parameter tensor, torch's operation order, hyper-parameter scalars formed in
+    libiefvad: ONE `iefvad_adamw_step_multi` launch for all parameter tensors of a group (`iefvad_adamw_step` per tensor when their step
+    counts or devices differ), torch's operation order, hyper-parameter scalars formed in
     double on the host as torch forms them.  A `torch.optim.Optimizer` subclass, so what the trainers do with their optimiser
     works unchanged: `MultiStepLR(optimizer, ...)` (ucf_train.py:29-33), `optimizer.state_dict()` in the checkpoint
     (ucf_train.py:141-149), `load_state_dict`, parameter groups, `zero_grad()`.  State per parameter as torch.optim.AdamW keeps
@@ -166,6 +168,7 @@ class AdamW(torch.optim.Optimizer):
             if group.get("amsgrad") or group.get("maximize"):
                 raise RuntimeError("iefvad_amd.losses.AdamW: amsgrad / maximize are not offered")
             b1, b2 = group["betas"]
+            todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -178,6 +181,45 @@ class AdamW(torch.optim.Optimizer):
                 g = p.grad
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.contiguous().float()
+                todo.append((p, g, st))
+            if not todo:
+                continue
+            # one launch for all tensors that share a device and a step count (in the trainers: all of them); stragglers one by one
+            steps = {int(st["step"].item()) for _, _, st in todo}
+            devs = {p.device for p, _, _ in todo}
+            if len(steps) == 1 and len(devs) == 1 and len(todo) > 1:
+                dev, step = next(iter(devs)), next(iter(steps))
+                tab = np.zeros((len(todo), 6), dtype=np.uint64)
+                chunk = 0
+                for i, (p, g, st) in enumerate(todo):
+                    tab[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), chunk)
+                    chunk += (p.numel() + 4095) // 4096
+                host = self.__dict__.setdefault("_table_host", {}).get(dev)
+                if host is None or host.shape[0] < len(todo):
+                    host = torch.empty(max(len(todo), 128), 6, dtype=torch.int64).pin_memory()
+                    self._table_host[dev] = host
+                    self.__dict__.setdefault("_table_dev", {})[dev] = torch.empty_like(host, device=dev)
+                tdev = self._table_dev[dev]
+                with torch.cuda.device(dev):
+                    # the pinned table is rewritten every step: wait until the previous step's copy has left it
+                    ev = self.__dict__.setdefault("_table_event", {}).get(dev)
+                    if ev is not None:
+                        ev.synchronize()
+                    host[:len(todo)].copy_(torch.from_numpy(tab.view(np.int64)))
+                    tdev[:len(todo)].copy_(host[:len(todo)], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._table_event[dev] = ev
+                    rc = lib.iefvad_adamw_step_multi(C.c_void_p(tdev.data_ptr()), len(todo), chunk, float(group["lr"]), float(b1), float(b2),
+                                                     float(group["eps"]), float(group["weight_decay"]), step,
+                                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                if rc != 0:
+                    raise RuntimeError("iefvad_adamw_step_multi: " + _lib.last_error())
+                self._keep = [g for _, g, _ in todo]          # converted gradients stay alive until the next step's launch has them
+                for p, _, _ in todo:
+                    torch.autograd.graph.increment_version(p)  # the kernel wrote through raw pointers: autograd and the model's weight cache must notice
+                continue
+            for p, g, st in todo:
                 with torch.cuda.device(p.device):
                     rc = lib.iefvad_adamw_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(st["exp_avg"].data_ptr()),
                                                C.c_void_p(st["exp_avg_sq"].data_ptr()), p.numel(), float(group["lr"]), float(b1), float(b2),

@@ -301,6 +301,21 @@ int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws, size_t tr
 int iefvad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                       double beta2, double eps, double weight_decay, int32_t step, void* stream);
 
+/* The same update for many tensors in ONE launch (a model of SURVEY.md Appendix B has 78 parameter tensors, most of them 768-element
+ * vectors): `table` is a DEVICE array of `count` entries, each with its four device pointers, its element count and the index of
+ * its first 4096-element chunk (first_chunk[0] = 0, first_chunk[i+1] = first_chunk[i] + ceil(n[i] / 4096)); total_chunks = the sum.
+ * All tensors take the same hyper-parameters and step count.  Element for element the arithmetic of iefvad_adamw_step. */
+typedef struct iefvad_adamw_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint64_t n;
+    uint64_t first_chunk;
+} iefvad_adamw_tensor;
+int iefvad_adamw_step_multi(const iefvad_adamw_tensor* table, int32_t count, uint64_t total_chunks, double lr, double beta1, double beta2,
+                            double eps, double weight_decay, int32_t step, void* stream);
+
 /* Host helper of the whole-video path (the loader side, /root/reference/data/dataset.py:34-52 + test.py:90-95's `.to(device)`):
  * dst[0 ..) = srcs[0] | srcs[1] | ... (nbytes[i] bytes each), copied by up to `threads` host threads.  `dst` is normally a
  * pinned staging buffer that one asynchronous copy then sends to the device as iefvad_forward_videos's img_rows / ev_rows.

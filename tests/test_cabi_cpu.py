@@ -33,18 +33,18 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_layout_matches_c_compiler(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "iefvad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "iefvad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(iefvad_config),sizeof(iefvad_weights),sizeof(iefvad_outputs),sizeof(iefvad_stage_times),'
                    'offsetof(iefvad_weights,ref_w1),offsetof(iefvad_weights,cls_w),offsetof(iefvad_config,lambda_ref),'
                    'sizeof(iefvad_train_options),offsetof(iefvad_train_options,seed),offsetof(iefvad_train_options,keep_mask),'
-                   'sizeof(iefvad_output_grads),sizeof(iefvad_weight_grads),sizeof(iefvad_unit_io),offsetof(iefvad_unit_io,w),offsetof(iefvad_unit_io,logits));return 0;}\n')
+                   'sizeof(iefvad_output_grads),sizeof(iefvad_weight_grads),sizeof(iefvad_unit_io),offsetof(iefvad_unit_io,w),offsetof(iefvad_unit_io,logits),sizeof(iefvad_adamw_tensor),offsetof(iefvad_adamw_tensor,first_chunk));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(L.Config), C.sizeof(L.Weights), C.sizeof(L.Outputs), C.sizeof(L.StageTimes),
             L.Weights.ref_w1.offset, L.Weights.cls_w.offset, L.Config.lambda_ref.offset,
             C.sizeof(L.TrainOptions), L.TrainOptions.seed.offset, L.TrainOptions.keep_mask.offset, C.sizeof(L.OutputGrads),
-            C.sizeof(L.WeightGrads), C.sizeof(L.UnitIO), L.UnitIO.w.offset, L.UnitIO.logits.offset]
+            C.sizeof(L.WeightGrads), C.sizeof(L.UnitIO), L.UnitIO.w.offset, L.UnitIO.logits.offset, 48, 40]      # iefvad_adamw_tensor: six 8-byte fields (losses.AdamW builds it as a [count, 6] uint64 table)
     assert got == want
 
 
