@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_t
 #define TN_SIX(x_, y_, c_) TN_MFMA(x_[2], y_[0], c_); TN_MFMA(x_[0], y_[2], c_); TN_MFMA(x_[1], y_[1], c_); TN_MFMA(x_[1], y_[0], c_); TN_MFMA(x_[0], y_[1], c_); TN_MFMA(x_[0], y_[0], c_)
 
     const int nk = R / TN_BK;
+#ifdef TN_PROBE_NOSPLIT
+    u32x4 pa[2][3] = {}, pb[2][3] = {};
+#endif
     const bool do_cs = args.colsum != nullptr && tn == 0;
     const int cs_c = t & 127, cs_h = t >> 7;
     float cs = 0.f;
@@ -96,11 +99,17 @@ __global__ __launch_bounds__(256, TN_NBUF == 3 ? 3 : 2) void iefvad_gemm_split_t
         if (kt + TN_NBUF - 1 < nk) dma(kt + TN_NBUF - 1, (kt + TN_NBUF - 1) % TN_NBUF);      // the buffer tile kt - 1 has left
         const float* imgA = tn_smem + (kt % TN_NBUF) * 2 * TN_TILE_FLOATS;
         const float* imgB = imgA + TN_TILE_FLOATS;
+#ifndef TN_PROBE_NOSPLIT
         u32x4 pa[2][3], pb[2][3];
+#endif
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const float* p = (f < 2 ? imgA : imgB) + 8 * h * 128 + 32 * (((f < 2 ? 2 * wm : 2 * wn) + (f & 1)) ^ h) + i;
             const f32x4 lo = {p[0], p[128], p[256], p[384]}, hi = {p[512], p[640], p[768], p[896]};
+#ifdef TN_PROBE_NOSPLIT      // timing probe only (wrong results): the fragment reads stay, the register split runs for the first k-tile only
+            asm volatile("" :: "v"(lo), "v"(hi));
+            if (kt == 0)
+#endif
             split8<false, 3>(lo, hi, f < 2 ? pa[f & 1] : pb[f & 1], 1.0f);
         }
 #pragma unroll
