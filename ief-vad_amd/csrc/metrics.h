@@ -86,7 +86,7 @@ __global__ __launch_bounds__(MT_THREADS) void iefvad_metric_hist_kernel(const un
         if (i < n) atomicAdd(&h[(unsigned)(in[i] >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];      // digit-major: one exclusive scan over the whole table gives the bases
+    hist[(size_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];      // digit-major: a digit's tile counts are one contiguous row
 }
 
 // The digit-major table [256 digits][tiles] becomes output bases in two levels: one workgroup per DIGIT scans its row of tile counts
