@@ -794,6 +794,14 @@ def _run_test(args, model, test_loader, maxlen, gt, device, label_map, attn, vis
     xd_test.py:155-159,170-173), which go to `log` when the caller supplies one (wandb itself is out of scope)."""
     model.to(device)
     model.eval()
+    if batch_chunks is None:
+        # default of the three entries: the packed route (the list walked inside the library, valid rows only) wherever it gives the
+        # SAME BITS as one forward per video -- compute "f32" (every tiling sums k in one order) and "bf16" (ring and row-block kernels
+        # are bit-identical); "bf16x6" / "fp16x3" pick their kernels by batch size, so they keep the reference's per-video pattern unless
+        # the caller asks (batch_chunks=64: scores move at the 1e-7 level, inside the fp32 gates).  Five times the per-video rate on a
+        # UCF-sized list (DESIGN.md section 5).
+        packed_same_bits = (getattr(model, "compute", None) in ("f32", "bf16") and torch.device(device).type == "cuda" and lanes == 1)
+        batch_chunks = 64 if packed_same_bits else 0
     scores, classes, wi, we = score_loader(model, test_loader, maxlen, device, args.dataset, label_map, batch_chunks,
                                            lanes=lanes)
     res = evaluate_scores(scores, classes, gt, args.dataset, verbose=True, normal_keys=normal_keys,
@@ -807,7 +815,7 @@ def _run_test(args, model, test_loader, maxlen, gt, device, label_map, attn, vis
 
 
 def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, label_map=None,
-         batch_chunks: int = 0, normal_keys=('Normal',), lanes: int = 1):
+         batch_chunks: Optional[int] = None, normal_keys=('Normal',), lanes: int = 1):
     """Counterpart of ROOT `test.py`'s `test()` (test.py:46-56; call site test.py:380-390): same positional order
     (..., device, attn, vis), Ano-AUC over every class but 'Normal' (test.py:336).  `label_map` is keyword-only in
     spirit: root test.py reads a global for the xd remap (test.py:81).  Returns (ROC1, AP1), or
@@ -819,7 +827,7 @@ def test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, 
 
 
 def ucf_test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=False, vis=False, *, log=None,
-             batch_chunks: int = 0, lanes: int = 1):
+             batch_chunks: Optional[int] = None, lanes: int = 1):
     """Drop-in for `train/ucf_test.py`'s `test` (ucf_test.py:16-26; call site ucf_train.py:130-139): positional order
     (..., device, attn, vis); Ano-AUC excludes BOTH 'Normal' and 'normal' (ucf_test.py:340); the per-class lines carry
     "Total Samples" (ucf_test.py:173-174).  `log` (e.g. `wandb.log`) receives the dicts the reference logs."""
@@ -830,7 +838,7 @@ def ucf_test(args, model, test_loader, maxlen, prompt_text, gt, device, attn=Fal
 
 
 def xd_test(args, model, test_loader, maxlen, prompt_text, gt, device, label_map, vis=False, attn=False, *, log=None,
-            batch_chunks: int = 0, lanes: int = 1):
+            batch_chunks: Optional[int] = None, lanes: int = 1):
     """Drop-in for `train/xd_test.py`'s `test` (xd_test.py:15-26; call site xd_train.py:102-112): `label_map` is the
     8th positional, then (vis, attn) -- the reverse of ucf_test's order; every video's class is
     `label_map[cls.split('-')[0]]` whatever args.dataset says (xd_test.py:68, unconditional); Ano-AUC excludes

@@ -194,3 +194,21 @@ def test_xd_test_entry_reproduces_the_reference_capture_through_the_hip_path(tmp
     ref_lines = [ln for ln in str(g["stdout"]).splitlines() if ln.strip()]
     assert out[0] == ref_lines[0]
     assert [ln for ln in out if " ROC:" in ln] == [ln for ln in ref_lines if " ROC:" in ln]
+
+
+def test_default_entry_takes_the_packed_route_with_the_per_video_bits(config1, capsys):
+    """`harness.test / ucf_test / xd_test` without `batch_chunks`: in compute "f32" (and "bf16") the packed route -- the list walked inside
+    the library -- gives the bits of one forward per video, so it is the default; "bf16x6" keeps the per-video pattern.  Checked here: the
+    default call's scores equal the explicit per-video call's bit for bit, and the capture's numbers."""
+    g, args, gt, sd = config1
+    for compute in ("f32", "bf16"):
+        model = gpu_model(sd, outputs="scores", compute=compute)
+        harness.ucf_test(args, model, harness.get_test_loader(args), 256, None, gt, "cuda:0")
+        dflt = harness.ucf_test.last_result["scores"]
+        harness.ucf_test(args, model, harness.get_test_loader(args), 256, None, gt, "cuda:0", batch_chunks=0)
+        per_video = harness.ucf_test.last_result["scores"]
+        for a, b in zip(dflt, per_video):
+            assert np.array_equal(a, b), compute
+        if compute == "f32":
+            assert np.abs(np.concatenate(dflt) - g["scores"]).max() <= H.TOL_SIGMOID
+    capsys.readouterr()
