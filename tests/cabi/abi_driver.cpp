@@ -4,6 +4,7 @@
 // iefvad_amd.synth.state_dict_keys(L, K), 3 floats of padding, then img [B,256,768], then ev [B,256,768].
 // Writes B*256 fp32 logits.  Exit code 0 on success; any ABI error prints iefvad_last_error().
 #include <hip/hip_runtime_api.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -164,7 +165,41 @@ int main(int argc, char** argv) {
         (void)hipFree(dgt); (void)hipFree(dm); (void)hipFree(mws);
     }
     printf("metrics AUC %.15f AP %.15f\n", h_metric[0], h_metric[1]);
-    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK\n", B, L, K, st.total_ms, st.gemm_launches);
+    // two of the VadCLIP-residue entries from plain C++: the distance adjacency against its closed form, and one graph
+    // convolution with that adjacency and an identity weight (out = adj x + x: checked on the host for one output row)
+    {
+        const int Tn = 128, Dn = 128;
+        float *dadj = nullptr, *dx = nullptr, *dw = nullptr, *dout = nullptr;
+        void* gws = nullptr;
+        const size_t gwsb = iefvad_gcn_workspace_bytes(1, Tn, Dn, Dn, 1);
+        HIPCK(hipMalloc((void**)&dadj, Tn * Tn * 4)); HIPCK(hipMalloc((void**)&dx, Tn * Dn * 4)); HIPCK(hipMalloc((void**)&dw, Dn * Dn * 4));
+        HIPCK(hipMalloc((void**)&dout, Tn * Dn * 4)); HIPCK(hipMalloc(&gws, gwsb));
+        std::vector<float> hx((size_t)Tn * Dn), hw((size_t)Dn * Dn, 0.f), hadj((size_t)Tn * Tn), ho((size_t)Tn * Dn);
+        for (size_t j = 0; j < hx.size(); ++j) hx[j] = (float)((j * 2654435761u >> 20) & 1023) / 1024.f - 0.5f;
+        for (int j = 0; j < Dn; ++j) hw[(size_t)j * Dn + j] = 1.f;
+        HIPCK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        ABICK(iefvad_distance_adj(1, Tn, dadj, stream));
+        ABICK(iefvad_gcn_forward(dx, dadj, dw, nullptr, nullptr, nullptr, 1, 0, 1, Tn, Dn, Dn, dout, gws, gwsb, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        HIPCK(hipMemcpy(hadj.data(), dadj, hadj.size() * 4, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(ho.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0.0;
+        for (int i = 0; i < Tn; ++i)
+            for (int j = 0; j < Tn; ++j) {
+                const double want = exp(-fabs((double)(i - j)) / exp(1.0));
+                if (fabs(hadj[(size_t)i * Tn + j] - want) > worst) worst = fabs(hadj[(size_t)i * Tn + j] - want);
+            }
+        if (worst > 1e-6) { fprintf(stderr, "iefvad_distance_adj differs from exp(-|i-j|/e) by %g\n", worst); return 8; }
+        for (int c = 0; c < Dn; c += 37) {
+            double want = hx[(size_t)5 * Dn + c];
+            for (int j = 0; j < Tn; ++j) want += (double)hadj[(size_t)5 * Tn + j] * hx[(size_t)j * Dn + c];
+            if (fabs(ho[(size_t)5 * Dn + c] - want) > 1e-4) { fprintf(stderr, "iefvad_gcn_forward row 5 col %d: %g vs %g\n", c, ho[(size_t)5 * Dn + c], want); return 8; }
+        }
+        (void)hipFree(dadj); (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(gws);
+    }
+
+    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK, auc_ap / distance_adj / gcn_forward OK\n", B, L, K, st.total_ms, st.gemm_launches);
     iefvad_destroy(h);
     (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);
     return 0;
