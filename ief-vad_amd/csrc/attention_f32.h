@@ -66,23 +66,23 @@ __device__ __forceinline__ void attention_f32_body(const AttnArgs& args, float* 
 #pragma unroll
         for (int s = 0; s < 12; ++s) q[s] = *(const f32x4*)(qp + 8 * s);
     }
-    // staging map: thread t moves chunks c = t + 256 j (j = 0..5) of a 64-row x 24-chunk tile
-    int srow[6], sch[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int c = t + 256 * j;
-        srow[j] = c / 24;
-        sch[j] = c - srow[j] * 24;
-    }
+    // staging map of a 64-row x 24-chunk (4 floats) tile: thread t moves rows (t >> 3) + 32 (j & 1), chunks (t & 7) + 8 (j >> 1), j = 0..5 --
+    // eight lanes cover one 128-byte line and every offset is a CONSTANT added to two per-thread bases (attention_split.h's map).  The
+    // first version kept a row and a chunk index per piece (c = t + 256 j, twelve registers): with them the kernel needed 263 registers
+    // and spilled seven, and a spill reload inside the tile loop is a vector-memory load that waits for the prefetched next tile.
+    const int srow0 = t >> 3, sch0 = t & 7;
+    const float* gsrc = qkv + (RG ? 0 : (size_t)srow0 * (3 * IEF_D)) + sch0 * 4;      // RG: the row is clamped per load
+    float* ldst = kv + srow0 * ATT_LDK + sch0 * 4;
     f32x4 stg[6];
     // tile ti: ti < 4 -> keys 64 ti .. of K (column block IEF_D), else of V (column block 2 IEF_D)
 #define ATT_LOAD(ti)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
-        stg[j] = *(const f32x4*)(qkv + (size_t)ATT_ROW(((ti) & 3) * ATT_TK + srow[j]) * (3 * IEF_D) +       \
-                                 ((ti) < 4 ? IEF_D : 2 * IEF_D) + sch[j] * 4);
+        stg[j] = *(const f32x4*)(gsrc + (size_t)(RG ? ATT_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + srow0)    \
+                                                      : ((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +   \
+                                 ((ti) < 4 ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
 #define ATT_WRITE(buf)                                                                                        \
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
-        *(f32x4*)(kv + (buf) * ATT_TILE + srow[j] * ATT_LDK + sch[j] * 4) = stg[j];
+        *(f32x4*)(ldst + (buf) * ATT_TILE + 32 * (j & 1) * ATT_LDK + 32 * (j >> 1)) = stg[j];
 
     ATT_LOAD(0)
     ATT_WRITE(0)
