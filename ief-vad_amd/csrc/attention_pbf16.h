@@ -44,6 +44,10 @@ __device__ __forceinline__ void attention_pbf16_body(const AttnBArgs& args, char
     }
     // fragment addressing
     const int ksw = (i >> 2) & 3;                   // swizzle of key row 32 kt + i
+    // the swizzle touches the two low bits of a chunk index only: chunk (2 s + h) ^ ksw = 4 (s >> 1) + (s odd ? (2 + h) ^ ksw : h ^ ksw) -- TWO
+    // per-lane byte offsets plus immediates instead of six registers (with six the row-compressed variant spilled two of them, and their
+    // reload -- a vector-memory load behind the K pieces of the NEXT item just requested -- made every item wait for that prefetch)
+    const int ko[2] = {(h ^ ksw) << 4, ((2 + h) ^ ksw) << 4};
     const int l16 = lane & 15;
     const int tr_row = l16 >> 2;
     const int tr_col = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
@@ -110,7 +114,7 @@ __device__ __forceinline__ void attention_pbf16_body(const AttnBArgs& args, char
                 const char* kp = kimg + (kt * 32 + i) * (IEF_DH * 2);
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
-                    const bf16x8 ka = *(const bf16x8*)(kp + (((2 * s + h) ^ ksw) << 4));
+                    const bf16x8 ka = *(const bf16x8*)(kp + ko[s & 1] + 64 * (s >> 1));      // chunk (2 s + h) ^ ksw
                     st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, q[s], st[kt], 0, 0, 0);
                 }
             }
