@@ -80,6 +80,8 @@ echo "== wire_dtype = BF16 (fp32 host rows rounded to bf16 by the staging thread
 IEFVAD_HOSTPIPE_TRACE=1 python3 "$R/tools/host_list_probe.py" --wire-bf16 >> "$O/host_list_probe.log" 2> "$O/host_list_trace_wire.log"
 grep hostpipe "$O/host_list_trace_wire.log" | tail -16 >> "$O/host_list_probe.log"
 echo "[10] persistent out_proj + LayerNorm kernel: phase stamps (diag build)"
+# the diag library is rebuilt from THIS tree (a stale one lacks the newer exports and lib.py refuses it)
+mkdir -p "$R/build" && make -s -B -C "$R/ief-vad_amd/csrc" EXTRA=-DOC_DIAG OUT=../../build/libiefvad_ocdiag.so > "$O/ocdiag_build.log" 2>&1
 if [ -f "$R/build/libiefvad_ocdiag.so" ]; then IEFVAD_LIB="$R/build/libiefvad_ocdiag.so" python3 "$R/tools/outproj_pdiag.py" > "$O/outproj_pchain_phase_stamps.log" 2>&1; fi
 for pz in 1 0; do
   IEFVAD_PERSIST=$pz python3 "$B" --compute bf16 --steps 3 --warmup 1 $QUIET 2>/dev/null | python3 -c "
