@@ -206,7 +206,13 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OC_LDS_BYTES);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OP_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OP_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_pchain_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 OP_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_outproj_ln_rchain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -826,9 +832,11 @@ static int launch_outproj_ln_chain(iefvad_handle* h, int l, bool whiten, const b
     if (rchain && persist) {
         for (int m = 0; m < 2; ++m) oa.p[m].stream = h->oproj_stream_r[m][l];
         hipLaunchKernelGGL(iefvad_outproj_ln_rchain_bf16_kernel, dim3(nblk < gx ? nblk : gx, 2), dim3(512), OR_LDS_BYTES, stream, oa);
-    } else if (persist && nblk >= 2 * gx)
-        hipLaunchKernelGGL(iefvad_outproj_ln_pchain_bf16_kernel, dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
-    else
+    } else if (persist && nblk >= 2 * gx && (y[0] != nullptr) == (y[1] != nullptr) && (yb[0] != nullptr) == (yb[1] != nullptr) && (y[0] || yb[0])) {
+        if (y[0] && yb[0]) hipLaunchKernelGGL((iefvad_outproj_ln_pchain_bf16_kernel<true, true>), dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
+        else if (y[0]) hipLaunchKernelGGL((iefvad_outproj_ln_pchain_bf16_kernel<true, false>), dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
+        else hipLaunchKernelGGL((iefvad_outproj_ln_pchain_bf16_kernel<false, true>), dim3(gx, 2), dim3(512), OP_LDS_BYTES, stream, oa);
+    } else
         hipLaunchKernelGGL(iefvad_outproj_ln_chain_bf16_kernel, dim3(rows / OC_BM, 2), dim3(512), OC_LDS_BYTES, stream, oa);
     tm.end(e);
     tm.gemm_launches += 1;

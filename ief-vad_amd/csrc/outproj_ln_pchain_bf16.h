@@ -26,6 +26,11 @@
 #define OP_LDS_BYTES (OP_AFF_OFF + 5 * IEF_D * 4)                        // 163,072 <= 163,840
 #define OP_DMA_PER_WAVE 12                                               // 6144 16-byte chunks / (8 waves x 64 lanes)
 
+// HAS_Y / HAS_YB (fp32 / bf16 output present) are template parameters, and the next image is requested for EVERY block, so that hipcc
+// knows how many vector-memory operations follow each residual request: with `if (P.y)` around the stores and `if (nxt < nblk)` around
+// the DMA it had to assume none, and its s_waitcnt for the residual rows of the next quarter (vmcnt counts in order, stores included)
+// also waited for the acknowledgements of the stores just issued -- and, in the last quarter, for the whole next image.
+template <bool HAS_Y, bool HAS_YB>
 __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(OutLnChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = (char*)smem;
@@ -37,6 +42,10 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
     const int nblk = args.M / OC_BM;
     const bool two = P.g2 != nullptr;
 
+    // De-phasing experiment (IEFVAD_OL_STAGGER = n: every other workgroup starts n x 8128 cycles late): all workgroups start together and
+    // a block takes the same time everywhere, so chip-wide the epilogues (all of a block's HBM traffic) coincide with each other.
+    if (args.stagger > 0 && (blockIdx.x & 1))
+        for (int i = 0; i < args.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // ---- once per workgroup: bias and the LayerNorms' affine terms -> LDS (5 x 768 floats, as in the round-3 kernel)
     {
         f32x4 aff[2];
@@ -85,23 +94,27 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
 #define OP_T(i)
 #define OP_T0()
 #endif
+    // The residual rows of a block's FIRST quarter are requested in the last quarter of the block before it (here for the first block):
+    // requested at the top of their own block they sat in front of the weight ring's refills, and a wave's vector-memory operations
+    // retire in order -- the ring (six pieces = 400 cycles ahead) stalled for one HBM latency at the start of every main loop.
+    f32x4 res[2][2][3];      // [quarter parity][row][16-byte piece]
+#define OP_FETCH_RES(m0_, quarter_)                                                                           \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                          \
+        const float* rp = P.R + (size_t)((m0_) + OP_PARK_ROWS * (quarter_) + 2 * wave + u) * IEF_D + 4 * lane; \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) res[(quarter_) & 1][u][j] = *(const f32x4*)(rp + 256 * j); \
+    }
+    OP_FETCH_RES((int)blockIdx.x * OC_BM, 0)
+    __builtin_amdgcn_sched_barrier(0);
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int m0 = blk * OC_BM;
         OP_T0();
-        // requests of this block, in the order they are needed: the first weight pieces, then the residual rows of the first quarter
+        // requests of this block: the first weight pieces
         f32x4 rg[OC_DEPTH];
 #pragma unroll
         for (int s = 0; s < OC_DEPTH; ++s) rg[s] = OP_LOAD(s);
-        f32x4 res[2][3];
-#define OP_FETCH_RES(quarter_)                                                                                \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                          \
-        const float* rp = P.R + (size_t)(m0 + OP_PARK_ROWS * (quarter_) + 2 * wave + u) * IEF_D + 4 * lane;  \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) res[u][j] = *(const f32x4*)(rp + 256 * j);            \
-    }
-        OP_FETCH_RES(0)
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's image pieces were requested before those 12 loads: at most 12 vector-memory operations may still be in flight
-        asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        // this wave's image pieces (and the first quarter's residual rows) were requested before those 6 loads
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         GB2_BARRIER();                        // every wave's pieces have landed (and the affine vectors of the first block)
         OP_T(0);
 
@@ -137,6 +150,12 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         GB2_BARRIER();                        // every wave is done with the image: it may be overwritten
         const int nxt = blk + (int)gridDim.x;
+#ifndef OP_PROBE_NORES
+        // Inside the epilogue the residual rows run TWO quarters ahead of their use (a CU's share of the HBM stream is ~10 bytes per
+        // cycle while the chip is busy: one quarter ahead, every quarter waited ~1.9 k cycles for its rows); nothing of it is issued
+        // in front of the weight ring.
+        OP_FETCH_RES(m0, 1)
+#endif
         OP_T(2);
 
         // ---- epilogue: four quarters of 16 rows; wave w normalises rows 2 w, 2 w + 1 of each quarter
@@ -148,15 +167,24 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) rcur[u][j] = res[u][j];
-            if (qt < 3) { OP_FETCH_RES(qt + 1) }     // in flight while this quarter is normalised
+                for (int j = 0; j < 3; ++j) rcur[u][j] = res[qt & 1][u][j];
+#ifndef OP_PROBE_NORES      // timing probe (wrong results): the residual rows of quarters 1 - 3 are not fetched
+            // (two quarters ahead; with quarters 0 AND 1 requested at the top of the block it was measured SLOWER, 16.6 -> 17.3 ms per step:
+            // the weight ring's pieces retire in order behind every HBM request in front of them; TRIED.md)
+            if (qt < 2) { OP_FETCH_RES(m0, qt + 2) }     // in flight while this quarter and the next are normalised
+#endif
+            // ... and the next block's first quarter (behind a workgroup's last block: its own rows again, requested and not used)
+            if (qt == 3) { OP_FETCH_RES((nxt < nblk ? nxt : blk) * OC_BM, 0) }
             // The next block's image is requested HERE, behind the last residual request: a wave's vector-memory operations retire
             // in order, so a residual row requested after the 12 KB of image pieces would arrive only when those have landed (the
             // first build issued them at the top of the epilogue and every quarter waited for the image: no overlap left).  Behind it
             // in the queue are only stores and the next block's first requests, which wait for the image anyway.
-            if (qt == 2 && nxt < nblk) { OP_IMAGE_DMA(nxt); }
+            // (behind the last block of a workgroup `nxt` lies outside the descriptor's range: the pieces are dropped by the range check)
+            if (qt == 2) { OP_IMAGE_DMA(nxt); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(OP_PROBE_NOBAR) || OP_PROBE_NOBAR < 2      // timing probes only (wrong results): -DOP_PROBE_NOBAR=1 drops the four end barriers, =2 the park barriers too
             GB2_BARRIER();                    // all parks of this quarter are complete
+#endif
             OP_T(3);
             f32x4 v[2][3];
 #pragma unroll
@@ -168,23 +196,32 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
                 }
             ln_rows<2>(v, affl + IEF_D - 4 * lane, affl + 2 * IEF_D - 4 * lane, lane, args.eps);       // ln_rows adds 4 lane itself
             if (two) ln_rows<2>(v, affl + 3 * IEF_D - 4 * lane, affl + 4 * IEF_D - 4 * lane, lane, args.eps);
+#ifdef OP_PROBE_NOSTORE     // timing probe (wrong results): the normalised rows are not stored
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) asm volatile("" :: "v"(v[u][j]));
+#else
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const size_t row = (size_t)(m0 + OP_PARK_ROWS * qt + 2 * wave + u);
-                if (P.y) {
+                if constexpr (HAS_Y) {
                     float* yp = P.y + row * IEF_D + 4 * lane;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) *(f32x4*)(yp + 256 * j) = v[u][j];
                 }
-                if (P.yb) {
+                if constexpr (HAS_YB) {
                     bf16_t* yb = P.yb + row * IEF_D + 4 * lane;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) *(bf16x4_t*)(yb + 256 * j) = to_bf16x4(v[u][j]);
                 }
             }
+#endif
             OP_T(4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef OP_PROBE_NOBAR
             GB2_BARRIER();                    // every reader is done with this quarter's parks: they may be overwritten
+#endif
             OP_T(3);
         }
 #ifdef OC_DIAG
