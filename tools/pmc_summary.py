@@ -21,7 +21,8 @@ for d in sys.argv[1:]:
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 print(f"{'kernel':44s} {'calls':>6s} {'avg us':>9s} {'clock GHz':>9s} {'mfma_util':>9s} {'wait_any':>8s} {'lds_conf':>9s} {'HBM GB/s':>9s}")
 for k in sorted(cnt, key=lambda k: -sum(dur[k])):
-    if not k.startswith("iefvad_"):
+    name = k[5:] if k.startswith("void ") else k      # template instantiations are listed as "void name<...>(...)"
+    if not name.startswith("iefvad_"):
         continue
     c = cnt[k]
     t_ns = mean(dur[k])
@@ -30,4 +31,4 @@ for k in sorted(cnt, key=lambda k: -sum(dur[k])):
     wait = mean(c.get("SQ_WAIT_ANY", [])) / mean(c.get("SQ_WAVE_CYCLES", [])) if c.get("SQ_WAVE_CYCLES") else float("nan")
     hbm = (2 * mean(c.get("FETCH_SIZE", [])) + mean(c.get("WRITE_SIZE", []))) * 1024 / t_ns
     ncalls = max(len(v) for v in c.values())
-    print(f"{k.split('(')[0][:44]:44s} {ncalls:6d} {t_ns / 1e3:9.1f} {clock:9.2f} {util:9.3f} {wait:8.3f} {mean(c.get('SQ_LDS_BANK_CONFLICT', [])):9.3g} {hbm:9.0f}")
+    print(f"{name.split('(')[0].replace(', ', ',')[:44]:44s} {ncalls:6d} {t_ns / 1e3:9.1f} {clock:9.2f} {util:9.3f} {wait:8.3f} {mean(c.get('SQ_LDS_BANK_CONFLICT', [])):9.3g} {hbm:9.0f}")
