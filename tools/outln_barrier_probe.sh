@@ -3,6 +3,9 @@
 # with -DOP_PROBE_NOBAR=1 (the four "quarter consumed" barriers dropped) and =2 (the four "quarter parked" barriers too) give WRONG
 # results and valid timings: the upper bound of any re-arrangement of the epilogue's synchronisation.
 #   make -C ief-vad_amd/csrc -B EXTRA=-DOP_PROBE_NOBAR=1 OUT=../../build/libiefvad_nobar1.so   (and =2 -> nobar2)
+# Other probe builds of the same kernel, passed as arguments: -DOP_PROBE_NOSTORE (the normalised rows are not stored), -DOP_PROBE_NORES (the
+# residual rows of quarters 1 - 3 are not requested), both; with -DOC_DIAG added, tools/outproj_pdiag.py prints their phase stamps.
+# bench.py accepts non-finite scores only under IEFVAD_TIMING_PROBE=1, which this script sets for the probe libraries alone.
 QUIET="--no-extra-modes --no-ucf-eval --no-cpu-baseline"
 LIBS=${@:-build/libiefvad_nobar1.so build/libiefvad_nobar2.so}
 for v in "" $LIBS "" $LIBS; do
