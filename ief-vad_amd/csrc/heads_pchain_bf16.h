@@ -81,9 +81,18 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_pchain_bf16_kernel(HeadsC
     HP_DMA(rsI, voA, HP_DMA_A, HP_A_OFF, blockIdx.x);
     HP_DMA(rsE, voB, HP_DMA_B, HP_B_OFF, blockIdx.x);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HC_DIAG      // phase sums per workgroup: top wait | phase 1 | barrier + DMA of x_e's last third | phase 2 (k < 512) | k = 512 barrier | phase 2 (k >= 512) | drain + barrier + next images' DMA issue | fusion epilogue
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0, dt1;
+#define HP_T(i) do { dt1 = __builtin_amdgcn_s_memtime(); dsum[i] += dt1 - dt0; dt0 = dt1; } while (0)
+#define HP_T0() do { dt0 = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HP_T(i)
+#define HP_T0()
+#endif
 
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int m0 = blk * HC_BM;
+        HP_T0();
         f32x4 rg[HC_DEPTH];
 #pragma unroll
         for (int s = 0; s < HC_DEPTH; ++s) rg[s] = HP_LOAD(s);
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_pchain_bf16_kernel(HeadsC
         // this wave's image pieces (A and B) were requested before those 8 loads
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         GB2_BARRIER();
+        HP_T(0);
 
         // acc[phase][2 hd + tile][a]: lane (m, q) holds row 16 a + m, columns 256 c3 + 32 wave + 16 tile + 4 q .. + 3
         f32x4 acc[2][4][4];
@@ -118,15 +128,20 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_pchain_bf16_kernel(HeadsC
         }                                                                                                           \
     }
         HP_MAIN(0, rdA, 16 * 1536, 0, OC_KT / 4)
+        HP_T(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         GB2_BARRIER();                        // every wave is done reading x_i: region A may be overwritten
         HP_DMA(rsE, voC, HP_DMA_C, HP_A_OFF, blk);
         __builtin_amdgcn_sched_barrier(0);
+        HP_T(2);
         HP_MAIN(1, rdB, 16 * 1024, 0, 4)      // k < 512 out of region B
+        HP_T(3);
         // the four DMA pieces above are older than every weight piece this wave has consumed in the last 14 k-steps: they have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         GB2_BARRIER();                        // ... in every wave
+        HP_T(4);
         HP_MAIN(1, rdC, 16 * 512, 4, OC_KT / 4)
+        HP_T(5);
 #undef HP_MAIN
 #pragma unroll
         for (int s = 0; s < HC_DEPTH; ++s) asm volatile("" :: "v"(rg[s]));      // the read-ahead (zero pad pieces) lands before its registers are reused
@@ -138,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_pchain_bf16_kernel(HeadsC
             HP_DMA(rsE, voB, HP_DMA_B, HP_B_OFF, nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
+        HP_T(6);
 
         // ---- epilogue, in registers (heads_chain_bf16.h's, operation for operation)
         float si[4] = {0.f, 0.f, 0.f, 0.f}, se[4] = {0.f, 0.f, 0.f, 0.f};
@@ -183,7 +199,12 @@ __global__ __launch_bounds__(512, 2) void iefvad_heads_pchain_bf16_kernel(HeadsC
                 }
             }
         }
+        HP_T(7);
     }
+#ifdef HC_DIAG
+    if (args.diag && t == 0)
+        for (int i = 0; i < 8; ++i) args.diag[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = dsum[i];
+#endif
 #undef HP_LOAD
 #undef HP_DMA
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase breakdown of a row-block kernel from in-kernel s_memtime stamps (a -DHC_DIAG -DIC_DIAG -DRC_DIAG build of the library,
-IEFVAD_LIB=build/libiefvad_<x>diag.so).  Usage: rowblock_diag.py heads|inproj|chain.  The stamps go to a buffer of their own; no
+IEFVAD_LIB=build/libiefvad_<x>diag.so).  Usage: rowblock_diag.py heads|heads_p|inproj|chain (heads_p: the persistent heads kernel, -DHC_DIAG).  The stamps go to a buffer of their own; no
 output depends on them; the LAST launch of the kernel in the forward is what remains in the buffer."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,11 @@ B = 1024
 PH = {"heads": (3 * (B * 256 // 64), "IEFVAD_HC_DIAG_PTR",
                 ["entry -> x_i image ready", "phase 1 main loop (mu_i, logvar_i)", "x_e image: loads, barrier, ds_write, barrier",
                  "phase 2 main loop (mu_e, logvar_e)", "epilogue (fusion in registers, stores)"]),
+      # the persistent heads kernel (heads_pchain_bf16.h): per-workgroup SUMS over its blocks, eight phases
+      "heads_p": (3 * 128, "IEFVAD_HC_DIAG_PTR",
+                  ["top of block: ring requests, image wait, barrier", "phase 1 main loop (x_i: mu_i, logvar_i)", "x_i-free barrier + DMA of x_e's last third",
+                   "phase 2 main loop, k < 512", "barrier in front of k = 512", "phase 2 main loop, k >= 512",
+                   "ring drain, barrier, next block's image DMA issue", "fusion epilogue in registers + stores"]),
       "inproj": (2 * (B * 256 // 64), "IEFVAD_IC_DIAG_PTR",
                  ["entry -> image ready", "pass q main loop", "pass q epilogue", "pass k main loop", "pass k epilogue",
                   "pass v main loop", "pass v epilogue"]),
@@ -42,6 +47,18 @@ if which == "chain":
             print(f"  {name:44s} {np.median(dd[:, i]):9.0f} {np.percentile(dd[:, i], 10):9.0f} {np.percentile(dd[:, i], 90):9.0f}")
         print(f"  {'whole projection':44s} {np.median(d[:, 8 * gi + 7] - d[:, 8 * gi]):9.0f}")
     print(f"  W1 start -> W2 start {np.median(d[:, 8] - d[:, 0]):9.0f}")
+    sys.exit(0)
+if which == "heads_p":
+    d = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    d = d[d.sum(axis=1) > 0]
+    nb = (B * 256 // 64) / (d.shape[0] / 3)
+    print(f"heads (persistent): {d.shape[0]} workgroups, {nb:.1f} blocks each; s_memtime ticks per BLOCK: median / p10 / p90")
+    tot = 0
+    for i, name in enumerate(PH[2]):
+        v = d[:, i] / nb
+        tot += np.median(v)
+        print(f"  {name:56s} {np.median(v):9.1f} {np.percentile(v, 10):9.1f} {np.percentile(v, 90):9.1f}")
+    print(f"  {'sum':56s} {tot:9.1f}")
     sys.exit(0)
 n = len(PH[2])
 d = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
