@@ -147,8 +147,10 @@ __global__ __launch_bounds__(512, 2) void iefvad_outproj_ln_pchain_bf16_kernel(O
 #pragma unroll
         for (int s = 0; s < OC_DEPTH; ++s) asm volatile("" :: "v"(rg[s]));      // the read-ahead (zero pad pieces) lands before its registers are reused
         OP_T(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        GB2_BARRIER();                        // every wave is done with the image: it may be overwritten
+        // No barrier here: the first quarter parks into a region of its own (its readers left it behind the previous block's last
+        // barrier), and the barrier that follows those parks is also the one that declares the image dead -- it is overwritten (by the
+        // next image's DMA) two quarters later.  The waves leave the main loop up to ~4 k cycles apart (wave 0 wins the weight stream's
+        // arbitration); the early ones now park and request their residual rows while the others finish.
         const int nxt = blk + (int)gridDim.x;
 #ifndef OP_PROBE_NORES
         // Inside the epilogue the residual rows run TWO quarters ahead of their use (a CU's share of the HBM stream is ~10 bytes per
