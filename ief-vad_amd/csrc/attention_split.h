@@ -63,8 +63,23 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (
 
 __device__ __forceinline__ int wave_id_of(int t) { return t >> 6; }
 
-template <bool F16, bool RG = false>
-__device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs) {
+// TRAIN (round 5, the train-mode forward of train.h): the same kernel, but the probabilities leave the chip -- autograd's backward needs
+// P = softmax(S) and Pd = dropout(P) ([chunks, 8, 256, 256] fp32 each; the backward products of backward.h read them) -- and q arrives
+// scaled by 1 / sqrt(96) only (the backward differentiates THAT scale), so the scores are multiplied by log2(e) inside the exp2.  In
+// the accumulator a lane holds one query's keys in groups of four consecutive ones: P and Pd go out as 16-byte stores.  The dropout
+// mask is the injected one (`keep`, one byte per element) or common.h's counter-based bits, element for element those of the
+// stand-alone softmax kernel.  Replaces three launches (S = q k^T on the fp32 MFMA kernel, softmax + dropout, Pd v) that wrote and
+// re-read S.
+struct AttnTrainArgs {
+    float* P[2];                    // per modality
+    float* Pd[2];                   // nullable: no dropout (p == 0 and no injected mask), Pd is P
+    const unsigned char* keep[2];   // nullable: injected masks, [chunks, 8, 256, 256] bytes (1 = keep)
+    unsigned long long seed[2];
+    float drop_p[2];
+};
+
+template <bool F16, bool RG = false, bool TRAIN = false>
+__device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs, const AttnTrainArgs* tx = nullptr) {
     constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
@@ -184,7 +199,8 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(F16 ? (st[kt][r] - mx) * s_inv2 : st[kt][r] - mx);   // log2 units
+                        const float p = __builtin_amdgcn_exp2f(F16 ? (st[kt][r] - mx) * s_inv2 : TRAIN ? (st[kt][r] - mx) * 1.4426950408889634f
+                                                                                                           : st[kt][r] - mx);   // log2 units
                         st[kt][r] = p;
                         sum += p;
                     }
@@ -194,6 +210,38 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                 for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
+                if constexpr (TRAIN) {
+                    // register 4 g + e of sub-tile kt is key 32 kt + 8 g + 4 h + e of query q0 + i
+                    const size_t prow = ((size_t)(chunk * IEF_H + head) * IEF_T + (q0 + i)) * IEF_T + 4 * h;
+                    float* Pp = tx->P[mod] + prow;
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(f32x4*)(Pp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
+                    if (tx->Pd[mod]) {           // uniform
+                        const float pdrop = tx->drop_p[mod];
+                        const float scale = (float)(1.0 / (1.0 - (double)pdrop));
+                        const unsigned thr = (unsigned)((double)pdrop * 16777216.0);
+                        const unsigned char* kp = tx->keep[mod];
+                        const unsigned long long seed = tx->seed[mod];
+                        float* Dp = tx->Pd[mod] + prow;
+#pragma unroll
+                        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const size_t idx0 = prow + 32 * kt + 8 * g;
+                                unsigned kb = 0;
+                                if (kp) kb = *(const unsigned*)(kp + idx0);      // four mask bytes (idx0 is a multiple of 4)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bool k = kp ? ((kb >> (8 * e)) & 0xffu) != 0 : dropout_bits(seed, idx0 + e) >= thr;
+                                    st[kt][4 * g + e] = k ? st[kt][4 * g + e] * scale : 0.f;
+                                }
+                                *(f32x4*)(Dp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
+                            }
+                    }
+                }
             }
         } else {
             // O[query][d] += sum over this tile's 64 keys of P[query][key] V[key][d]
@@ -257,6 +305,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_kernel(AttnArgs
 __global__ __launch_bounds__(256, 2) void iefvad_attention_split_rows_kernel(AttnArgs args) {
     extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
     attention_split_body<false, true>(args, kvs);
+}
+
+// train-mode forward: P and dropout(P) are stored (train.h)
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_train_kernel(AttnArgs args, AttnTrainArgs tx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<false, false, true>(args, kvs, &tx);
 }
 
 // fp16x3

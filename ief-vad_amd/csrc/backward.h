@@ -191,16 +191,7 @@ __global__ __launch_bounds__(256) void iefvad_transpose_f32_kernel(const float* 
 // ------------------------------------------------------------------------------------------------------------------------
 // attention probabilities, train mode
 // ------------------------------------------------------------------------------------------------------------------------
-// counter-based uniform bits for the dropout mask: one 64-bit mix (splitmix64's finaliser) of (seed, element index); the same
-// (seed, index) always gives the same bit, so nothing but the seed has to be remembered.  torch draws its mask from Philox in an
-// order of its own: a p > 0 run is statistically, not bit-wise, the reference's ("parity unpinned"; p = 0 and injected masks are pinned).
-__device__ __forceinline__ unsigned dropout_bits(unsigned long long seed, unsigned long long idx) {
-    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x = x ^ (x >> 31);
-    return (unsigned)(x >> 40);                  // 24 uniform bits
-}
+// (the counter-based mask generator `dropout_bits` lives in common.h: the fused train-mode attention kernel draws the same bits)
 
 // One wavefront per score row (256 keys, 4 per lane).  S holds q k^T / sqrt(96) (q is pre-scaled by the in_proj epilogue, as
 // F.multi_head_attention_forward scales q before the bmm).  P = softmax(S) is written over S; Pd = dropout(P) (kept entries

@@ -118,3 +118,20 @@ __device__ __forceinline__ int amax_exponent(float amax) {
     if (e == 0 || e == 0xff) return 13;
     return e - 127 < IEF_AMAX_EXP_CAP ? e - 127 : IEF_AMAX_EXP_CAP;
 }
+
+// Counter-based uniform bits for the attention-dropout mask (train mode): a 32-bit mix (murmur3's finaliser, twice) of (seed, element
+// index); the same (seed, index) always gives the same bits, so nothing but the seed has to be remembered, and the fused attention
+// kernel (attention_split.h, TRAIN) and the stand-alone softmax kernel (backward.h) draw the same mask.  torch draws its mask from
+// Philox in an order of its own: a p > 0 run is statistically, not bit-wise, the reference's ("parity unpinned"; p = 0 and injected
+// masks are pinned).  Round 5 replaced the 64-bit splitmix finaliser (twelve quarter-rate 32-bit multiplies per element: more VALU
+// time than the attention kernel's MFMAs) by this form: four.  `dropout_mix` is the per-row part.
+__device__ __forceinline__ unsigned fmix32(unsigned x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    return x ^ (x >> 16);
+}
+__device__ __forceinline__ unsigned dropout_bits(unsigned long long seed, unsigned long long idx) {
+    const unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
+    const unsigned a = fmix32(lo ^ (unsigned)seed);
+    return fmix32(a + (unsigned)(seed >> 32) + hi * 0x9E3779B1u) >> 8;      // 24 uniform bits
+}

@@ -344,6 +344,31 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         }
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
 
+        // bf16x6: S = q k^T -> softmax -> dropout -> Pd v in ONE launch for both modalities (attention_split.h, TRAIN: the eval kernel
+        // with P and Pd stored for the backward); IEFVAD_TRAIN_ATTN=unfused keeps the three launches below (A/B).  The fp32 arithmetic
+        // keeps them: its products stay on the fp32 MFMA instruction.
+        const char* attn_env = getenv("IEFVAD_TRAIN_ATTN");      // read per call: the A/B test flips it between two forwards
+        const bool attn_unfused = attn_env && attn_env[0] == 'u';
+        if (c.compute == IEFVAD_COMPUTE_BF16X6 && !attn_unfused) {
+            AttnArgs aa;
+            AttnTrainArgs tx;
+            memset(&aa, 0, sizeof(aa));
+            memset(&tx, 0, sizeof(tx));
+            aa.nchunks = B;
+            for (int m = 0; m < 2; ++m) {
+                const float pdrop = opt->dropout_p[m][l];
+                const bool drop = pdrop > 0.f || opt->keep_mask;
+                aa.qkv[m] = ws + t.qkv[m][l];
+                aa.out[m] = ws + t.att[m][l];
+                tx.P[m] = ws + t.P[m][l];
+                tx.Pd[m] = drop ? ws + t.Pd[m][l] : nullptr;
+                tx.keep[m] = opt->keep_mask ? opt->keep_mask + ((size_t)m * L + l) * t.PU : nullptr;
+                tx.seed[m] = opt->seed * 0x100000001B3ull + (unsigned long long)(m * IEFVAD_MAX_LAYERS + l + 1) * 0x9E3779B97F4A7C15ull;
+                tx.drop_p[m] = pdrop;
+            }
+            hipLaunchKernelGGL(iefvad_attention_split_train_kernel, dim3(IEF_H, 2, 2 * B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
+            HIP_TRY(hipGetLastError());
+        } else
         for (int m = 0; m < 2; ++m) {
             float* qkv = ws + t.qkv[m][l];
             const float pdrop = opt->dropout_p[m][l];

@@ -187,6 +187,44 @@ def test_gradients_are_bit_reproducible_and_accumulate():
         assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=1e-12), n
 
 
+@pytest.mark.parametrize("mode", ["library_generator", "injected_mask", "no_dropout"])
+def test_fused_train_attention_equals_the_three_launch_path(mode, monkeypatch):
+    """bf16x6 train-mode forward: ONE attention launch per layer (attention_split.h TRAIN: S -> softmax -> dropout -> Pd v with P and Pd
+    stored) against the three launches it replaced (IEFVAD_TRAIN_ATTN=unfused: fp32-MFMA products, stand-alone softmax + dropout): same
+    mask element for element (injected, or the counter-based bits of common.h), all eight outputs and every parameter gradient at the
+    fp32 gates.  /root/reference/model/imf_vad.py:69-72,115,121 under model.train()."""
+    p = 0.0 if mode == "no_dropout" else 0.1
+    B, L = 3, 2
+    img, ev, labels, lengths = batch(52, B)
+    res = {}
+    for which in ("fused", "unfused"):
+        if which == "unfused":
+            monkeypatch.setenv("IEFVAD_TRAIN_ATTN", "unfused")
+        else:
+            monkeypatch.delenv("IEFVAD_TRAIN_ATTN", raising=False)
+        model, _ = make_model(41, L, 2, "StudentT", 8, "bf16x6", p)
+        if mode == "injected_mask":
+            model.dropout_mask = torch.from_numpy(synth.make_dropout_mask(7, L, B, p)).cuda()
+        model.dropout_seed = 4321
+        model.train()
+        out = model(img, ev, None, None, lengths)
+        total = losses.training_loss(out, labels, lengths, "StudentT", 8, 1.0, 1.0)
+        total.backward()
+        res[which] = ({k: v.detach().clone() for k, v in out.items()}, {n: q.grad.clone() for n, q in model.named_parameters()}, float(total.detach()))
+    (o1, g1, l1), (o2, g2, l2) = res["fused"], res["unfused"]
+    assert abs(l1 - l2) <= 1e-5 * abs(l2)
+    for k in o1:
+        assert float((o1[k] - o2[k]).abs().max()) <= H.TOL_BIG, k
+    for n in g1:
+        scale = float(g2[n].abs().max())
+        assert float((g1[n] - g2[n]).abs().max()) <= 1e-4 * scale + 1e-9, n
+    if mode != "no_dropout":       # the mask did something: the outputs differ from a no-dropout forward
+        model, _ = make_model(41, L, 2, "StudentT", 8, "bf16x6", 0.0)
+        model.train()
+        o0 = model(img, ev, None, None, lengths)
+        assert float((o0["image_mu"].detach() - o1["image_mu"]).abs().mean()) > 1e-4
+
+
 def test_train_forward_without_dropout_equals_the_eval_forward():
     """p = 0: train() changes nothing in the reference's forward; here the train path computes attention on other kernels (scores
     and probabilities materialised) -- fp32 gates against the eval path, all eight outputs."""
