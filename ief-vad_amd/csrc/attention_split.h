@@ -76,10 +76,18 @@ struct AttnTrainArgs {
     const unsigned char* keep[2];   // nullable: injected masks, [chunks, 8, 256, 256] bytes (1 = keep)
     unsigned long long seed[2];
     float drop_p[2];
+    // BWD (the first half of the same kernel with other operands: d Pd^T = v d att^T per (chunk, head), then the softmax backward on the
+    // accumulators -- a lane holds a whole query row, so rowsum(Pd .* d Pd) is an in-lane sum and one shfl_xor):
+    // d S = Pd .* d Pd - P rowsum(Pd .* d Pd) leaves as fp32; replaces the d Pd product and the stand-alone softmax backward
+    const float* dO[2];             // d att: [rows, 768], head h at columns 96 h
+    float* dS[2];                   // [chunks, 8, 256, 256]
 };
 
-template <bool F16, bool RG = false, bool TRAIN = false>
+// MODE 0: eval; 1: train-mode forward (TRAIN); 2: train-mode backward, d S (BWD)
+template <bool F16, bool RG = false, int MODE = 0>
 __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs, const AttnTrainArgs* tx = nullptr) {
+    constexpr bool TRAIN = MODE == 1, BWD = MODE == 2;
+    constexpr int NT = BWD ? 4 : 8;                  // staged 64-key tiles: K then V (BWD: v only, in the K-plane layout)
     constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
@@ -124,7 +132,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
         stg[j] = *(const f32x4*)(((ti) < 4 ? gsrc_k : gsrc_v) + (size_t)(RG ? ATS_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + ((ti) < 4 ? srow_k : srow_v)) \
                                                       : ((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +       \
-                                 ((ti) < 4 ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
+                                 ((ti) < 4 && !BWD ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
     // split the staged fp32 chunks and write the three bf16 plane images of tile ti into buffer `buf`
 #define ATS_WRITE(ti, buf)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
@@ -144,7 +152,8 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     // Q planes (B operand of K Q^T): lane (i, h) holds Q[q0 + i][16 s + 8 h .. +7], s = 0..5
     u32x4 qp[6][NP];
     {
-        const float* qptr = qkv + (size_t)ATS_ROW(q0 + i) * (3 * IEF_D) + 8 * h;
+        const float* qptr = BWD ? tx->dO[mod] + (size_t)(row0 + q0 + i) * IEF_D + head * IEF_DH + 8 * h
+                                : qkv + (size_t)ATS_ROW(q0 + i) * (3 * IEF_D) + 8 * h;
 #pragma unroll
         for (int s = 0; s < 6; ++s)
             split8<F16, NP>(*(const f32x4*)(qptr + 16 * s), *(const f32x4*)(qptr + 16 * s + 4), qp[s], qs);
@@ -169,8 +178,8 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     const int tr_off = (4 * h + (l16 >> 2)) * ATS_VROW + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
 
 #pragma unroll
-    for (int ti = 0; ti < 8; ++ti) {
-        if (ti + 1 < 8) { ATS_LOAD(ti + 1) }
+    for (int ti = 0; ti < NT; ++ti) {
+        if (ti + 1 < NT) { ATS_LOAD(ti + 1) }
         const bf16_t* T = kvs + (ti & 1) * ATS_BUF;
         if (ti < 4) {
             // S^T[key][query] = sum_d K[key][d] Q[query][d] for the two 32-key sub-tiles of this tile
@@ -185,7 +194,37 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     ATS_SIX(ka, qp[s], st[2 * ti + u]);
                 }
             }
-            if (ti == 3) {
+            if (ti == 3 && BWD) {
+                // st = d Pd[query q0 + i][key] (128 keys in this lane, 128 in lane i + 32); register 4 g + e of sub-tile kt is key
+                // 32 kt + 8 g + 4 h + e
+                const size_t prow = ((size_t)(chunk * IEF_H + head) * IEF_T + (q0 + i)) * IEF_T + 4 * h;
+                const float* Pp = tx->P[mod] + prow;
+                const float* Dp = tx->Pd[mod] + prow;           // the caller passes P when no dropout was in force
+                float d = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 pd = *(const f32x4*)(Dp + 32 * kt + 8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st[kt][4 * g + e] *= pd[e]; d += st[kt][4 * g + e]; }
+                        if ((kt & 1) && g == 3) __builtin_amdgcn_sched_barrier(0);      // at most eight 16-byte loads ahead: hipcc otherwise hoists all 32 and spills
+                    }
+                d += __shfl_xor(d, 32, 64);
+                float* Sp = tx->dS[mod] + prow;
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 pv = *(const f32x4*)(Pp + 32 * kt + 8 * g);
+                        f32x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = st[kt][4 * g + e] - pv[e] * d;
+                        *(f32x4*)(Sp + 32 * kt + 8 * g) = o4;
+                        if ((kt & 1) && g == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            if (ti == 3 && !BWD) {
                 // softmax over the 256 keys of query q0 + i: 128 values in this lane, 128 in lane i + 32
                 // (fp16x3: the accumulators hold s^2 x the scores; exp2((st - mx) s^-2) in one fma)
                 float mx = st[0][0];
@@ -270,13 +309,14 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     }
                 }
         }
-        if (ti + 1 < 8) {
+        if (ti + 1 < NT) {
             ATS_WRITE(ti + 1, (ti + 1) & 1)     // the other buffer: its previous tile (ti - 1) was released by the last barrier
             __syncthreads();
         }
     }
 #undef ATS_LOAD
 #undef ATS_WRITE
+    if constexpr (BWD) return;
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
     float om = 0.f;
 #pragma unroll
@@ -310,7 +350,13 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_rows_kernel(Att
 // train-mode forward: P and dropout(P) are stored (train.h)
 __global__ __launch_bounds__(256, 2) void iefvad_attention_split_train_kernel(AttnArgs args, AttnTrainArgs tx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
-    attention_split_body<false, false, true>(args, kvs, &tx);
+    attention_split_body<false, false, 1>(args, kvs, &tx);
+}
+
+// train-mode backward: d S from d att, v, P and dropout(P) (train.h)
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_ds_kernel(AttnArgs args, AttnTrainArgs tx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<false, false, 2>(args, kvs, &tx);
 }
 
 // fp16x3

@@ -583,12 +583,29 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             const long long sQ = (long long)IEF_T * 3 * IEF_D, sP1 = (long long)IEF_H * IEF_T * IEF_T, sP2 = (long long)IEF_T * IEF_T,
                             sA = (long long)IEF_T * IEF_D;
             BgemmArgs a;
+            // bf16x6: d S = Pd .* d Pd - P rowsum(Pd .* d Pd) with d Pd = d att v^T in ONE launch (attention_split.h, BWD: the product on the
+            // split arithmetic, the softmax backward on its accumulators); IEFVAD_TRAIN_ATTN=unfused keeps the product on the fp32 MFMA
+            // kernel and the stand-alone softmax backward (A/B)
+            const char* attn_env = getenv("IEFVAD_TRAIN_ATTN");
+            const bool ds_fused = h->cfg.compute == IEFVAD_COMPUTE_BF16X6 && !(attn_env && attn_env[0] == 'u');
+            if (ds_fused) {
+                AttnArgs aa;
+                AttnTrainArgs tx;
+                memset(&aa, 0, sizeof(aa));
+                memset(&tx, 0, sizeof(tx));
+                aa.nchunks = B;
+                aa.qkv[0] = qkv;
+                tx.dO[0] = datt; tx.P[0] = const_cast<float*>(P); tx.Pd[0] = const_cast<float*>(Pd); tx.dS[0] = dP;
+                hipLaunchKernelGGL(iefvad_attention_split_ds_kernel, dim3(IEF_H, 2, B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
+                HIP_TRY(hipGetLastError());
+            } else {
             // d Pd = d att v^T
             memset(&a, 0, sizeof(a));
             a.A = datt; a.B = qkv + 2 * IEF_D; a.C = dP;
             a.M = IEF_T; a.N = IEF_T; a.K = IEF_DH; a.lda = IEF_D; a.ldb = 3 * IEF_D; a.ldc = IEF_T;
             a.a1 = sA; a.a2 = IEF_DH; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sP1; a.c2 = sP2; a.nz2 = IEF_H; a.alpha = 1.f;
             if (int rc = launch_bgemm(a, true, true, B * IEF_H, stream)) return rc;
+            }
             // d v = Pd^T d att
             memset(&a, 0, sizeof(a));
             a.A = Pd; a.B = datt; a.C = dqkv + 2 * IEF_D;
@@ -596,7 +613,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             a.a1 = sP1; a.a2 = sP2; a.b1 = sA; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
             if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
             // d S = Pd .* d Pd - P rowsum(Pd .* d Pd)
-            {
+            if (!ds_fused) {
                 const long long srows = (long long)B * IEF_H * IEF_T;
                 hipLaunchKernelGGL(iefvad_softmax_bwd_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, stream, P, Pd, dP, srows);
                 HIP_TRY(hipGetLastError());
