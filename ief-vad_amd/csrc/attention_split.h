@@ -81,13 +81,17 @@ struct AttnTrainArgs {
     // d S = Pd .* d Pd - P rowsum(Pd .* d Pd) leaves as fp32; replaces the d Pd product and the stand-alone softmax backward
     const float* dO[2];             // d att: [rows, 768], head h at columns 96 h
     float* dS[2];                   // [chunks, 8, 256, 256]
+    // ... and the second half runs on d S where the forward runs on P: d q = q_scale d S k (the k rows staged where the forward stages
+    // v), written into the q block of d qkv [rows, 2304]; the stand-alone d q product (which re-read d S) is gone as well
+    float* dQ[2];
+    float q_scale;
 };
 
 // MODE 0: eval; 1: train-mode forward (TRAIN); 2: train-mode backward, d S (BWD)
 template <bool F16, bool RG = false, int MODE = 0>
 __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs, const AttnTrainArgs* tx = nullptr) {
     constexpr bool TRAIN = MODE == 1, BWD = MODE == 2;
-    constexpr int NT = BWD ? 4 : 8;                  // staged 64-key tiles: K then V (BWD: v only, in the K-plane layout)
+    constexpr int NT = 8;                            // staged 64-key tiles: k then v (BWD: v, then k)
     constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
     const int head = blockIdx.x, qhalf = blockIdx.y, chunk = blockIdx.z % args.nchunks, mod = blockIdx.z / args.nchunks;
@@ -132,7 +136,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                             \
         stg[j] = *(const f32x4*)(((ti) < 4 ? gsrc_k : gsrc_v) + (size_t)(RG ? ATS_ROW(((ti) & 3) * ATT_TK + 32 * (j & 1) + ((ti) < 4 ? srow_k : srow_v)) \
                                                       : ((ti) & 3) * ATT_TK + 32 * (j & 1)) * (3 * IEF_D) +       \
-                                 ((ti) < 4 && !BWD ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
+                                 (((ti) < 4) != BWD ? IEF_D : 2 * IEF_D) + 32 * (j >> 1));
     // split the staged fp32 chunks and write the three bf16 plane images of tile ti into buffer `buf`
 #define ATS_WRITE(ti, buf)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
@@ -208,7 +212,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                         const f32x4 pd = *(const f32x4*)(Dp + 32 * kt + 8 * g);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { st[kt][4 * g + e] *= pd[e]; d += st[kt][4 * g + e]; }
-                        if ((kt & 1) && g == 3) __builtin_amdgcn_sched_barrier(0);      // at most eight 16-byte loads ahead: hipcc otherwise hoists all 32 and spills
+                        if (g == 3) __builtin_amdgcn_sched_barrier(0);      // at most four 16-byte loads ahead: hipcc otherwise hoists all 32 and spills
                     }
                 d += __shfl_xor(d, 32, 64);
                 float* Sp = tx->dS[mod] + prow;
@@ -217,11 +221,10 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 pv = *(const f32x4*)(Pp + 32 * kt + 8 * g);
-                        f32x4 o4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = st[kt][4 * g + e] - pv[e] * d;
-                        *(f32x4*)(Sp + 32 * kt + 8 * g) = o4;
-                        if ((kt & 1) && g == 3) __builtin_amdgcn_sched_barrier(0);
+                        for (int e = 0; e < 4; ++e) st[kt][4 * g + e] -= pv[e] * d;      // d S stays in the registers: the A operand of d q = d S k
+                        *(f32x4*)(Sp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
+                        if (g == 3) __builtin_amdgcn_sched_barrier(0);
                     }
             }
             if (ti == 3 && !BWD) {
@@ -316,8 +319,17 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     }
 #undef ATS_LOAD
 #undef ATS_WRITE
-    if constexpr (BWD) return;
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
+    if constexpr (BWD) {
+        float* dq = tx->dQ[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
+        const float qsc = tx->q_scale;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dq[(size_t)(q0 + (r & 3) + 8 * (r >> 2) + 4 * h) * (3 * IEF_D) + dt * 32 + i] = o[dt][r] * qsc;
+        return;
+    }
     float om = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)

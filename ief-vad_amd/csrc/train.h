@@ -596,6 +596,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
                 aa.nchunks = B;
                 aa.qkv[0] = qkv;
                 tx.dO[0] = datt; tx.P[0] = const_cast<float*>(P); tx.Pd[0] = const_cast<float*>(Pd); tx.dS[0] = dP;
+                tx.dQ[0] = dqkv; tx.q_scale = qscale;
                 hipLaunchKernelGGL(iefvad_attention_split_ds_kernel, dim3(IEF_H, 2, B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
                 HIP_TRY(hipGetLastError());
             } else {
@@ -618,12 +619,14 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
                 hipLaunchKernelGGL(iefvad_softmax_bwd_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, stream, P, Pd, dP, srows);
                 HIP_TRY(hipGetLastError());
             }
-            // d q (before the 1/sqrt(96) scale) = qscale * d S k
+            // d q (before the 1/sqrt(96) scale) = qscale * d S k  (ds_fused: done by the same launch, on the d S in its registers)
+            if (!ds_fused) {
             memset(&a, 0, sizeof(a));
             a.A = dP; a.B = qkv + IEF_D; a.C = dqkv;
             a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = 3 * IEF_D; a.ldc = 3 * IEF_D;
             a.a1 = sP1; a.a2 = sP2; a.b1 = sQ; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = qscale;
             if (int rc = launch_bgemm(a, true, false, B * IEF_H, stream)) return rc;
+            }
             // d k = d S^T q_scaled
             memset(&a, 0, sizeof(a));
             a.A = dP; a.B = qkv; a.C = dqkv + IEF_D;
