@@ -198,34 +198,70 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     ATS_SIX(ka, qp[s], st[2 * ti + u]);
                 }
             }
+            // TRAIN / BWD: the [256 x 256] tensors (P, Pd, d S) cross the chip boundary ROW-MAJOR.  In the accumulator a lane holds its
+            // query's keys in groups of four, so direct 16-byte accesses touch 32 rows per instruction (32-byte pieces: the first build's
+            // forward ran at 1.9 TB/s of stores).  After tile 3 the tile buffer that held it is dead until tile 5 is written: every wave
+            // takes a [32 queries][64 keys + 4] fp32 slice of it (8.5 KB) and moves 64 keys at a time through it -- the global side is
+            // then four whole 256-byte row segments per instruction.  Wave-private: no workgroup barrier beyond the one that frees the
+            // buffer.
+#define ATS_TL(row_, col_) (tl + (row_) * 68 + (col_))
+            // registers (st) -> slice -> memory rows q0 .. q0 + 31 through descriptor `rs_` (based at row q0, key 0; 32 KB): the lane's
+            // part of the address is ONE register (vrow), the rest scalar offsets -- 64-bit addresses per (row group, batch) cost 16 spills
+#define ATS_PUT_ROWS(rs_)                                                                                              \
+    _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) {                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                  \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                              \
+                *(f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h) = f32x4{st[2 * b4 + u][4 * g], st[2 * b4 + u][4 * g + 1],   \
+                                                                   st[2 * b4 + u][4 * g + 2], st[2 * b4 + u][4 * g + 3]}; \
+        _Pragma("unroll") for (int sr = 0; sr < 8; ++sr)                                                               \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)ATS_TL(4 * sr + (lane >> 4), (lane & 15) * 4)), \
+                                                   rs_, vrow, (4 * sr * IEF_T + 64 * b4) * 4, 0);                      \
+    }
+            // memory rows -> slice; afterwards ATS_TL(i, 32 u + 8 g + 4 h) is this lane's group g of sub-tile 2 b4 + u
+#define ATS_GET_ROWS(rs_, b4_)                                                                                         \
+    _Pragma("unroll") for (int sr = 0; sr < 8; ++sr)                                                                   \
+        *(f32x4*)ATS_TL(4 * sr + (lane >> 4), (lane & 15) * 4) =                                                       \
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, vrow, (4 * sr * IEF_T + 64 * (b4_)) * 4, 0));
+#define ATS_ROWS_RSRC(ptr_) __builtin_amdgcn_make_buffer_rsrc((void*)((ptr_) + wrow), 0, 32 * IEF_T * 4, 0x00020000)
             if (ti == 3 && BWD) {
                 // st = d Pd[query q0 + i][key] (128 keys in this lane, 128 in lane i + 32); register 4 g + e of sub-tile kt is key
                 // 32 kt + 8 g + 4 h + e
-                const size_t prow = ((size_t)(chunk * IEF_H + head) * IEF_T + (q0 + i)) * IEF_T + 4 * h;
-                const float* Pp = tx->P[mod] + prow;
-                const float* Dp = tx->Pd[mod] + prow;           // the caller passes P when no dropout was in force
+                __syncthreads();                   // every wave is done with tile 3: its buffer is scratch now
+                float* tl = (float*)(kvs + (3 & 1) * ATS_BUF) + wave * (32 * 68);
+                const size_t wrow = ((size_t)(chunk * IEF_H + head) * IEF_T + __builtin_amdgcn_readfirstlane(q0)) * IEF_T;
+                const int vrow = ((lane >> 4) * IEF_T + (lane & 15) * 4) * 4;
+                const auto Pw = ATS_ROWS_RSRC(tx->P[mod]);
+                const auto Dw = ATS_ROWS_RSRC(tx->Pd[mod]);     // the caller passes P when no dropout was in force
                 float d = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < 8; ++kt)
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    ATS_GET_ROWS(Dw, b4)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 pd = *(const f32x4*)(Dp + 32 * kt + 8 * g);
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { st[kt][4 * g + e] *= pd[e]; d += st[kt][4 * g + e]; }
-                        if (g == 3) __builtin_amdgcn_sched_barrier(0);      // at most four 16-byte loads ahead: hipcc otherwise hoists all 32 and spills
-                    }
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 pd = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { st[2 * b4 + u][4 * g + e] *= pd[e]; d += st[2 * b4 + u][4 * g + e]; }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);      // one batch of loads ahead at most: hipcc otherwise hoists all four and spills
+                }
                 d += __shfl_xor(d, 32, 64);
-                float* Sp = tx->dS[mod] + prow;
 #pragma unroll
-                for (int kt = 0; kt < 8; ++kt)
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    ATS_GET_ROWS(Pw, b4)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 pv = *(const f32x4*)(Pp + 32 * kt + 8 * g);
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) st[kt][4 * g + e] -= pv[e] * d;      // d S stays in the registers: the A operand of d q = d S k
-                        *(f32x4*)(Sp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
-                        if (g == 3) __builtin_amdgcn_sched_barrier(0);
-                    }
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 pv = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) st[2 * b4 + u][4 * g + e] -= pv[e] * d;      // d S stays in the registers: the A operand of d q = d S k
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const auto Sw = ATS_ROWS_RSRC(tx->dS[mod]);
+                ATS_PUT_ROWS(Sw)
             }
             if (ti == 3 && !BWD) {
                 // softmax over the 256 keys of query q0 + i: 128 values in this lane, 128 in lane i + 32
@@ -254,20 +290,19 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     for (int r = 0; r < 16; ++r) st[kt][r] *= inv;
                 if constexpr (TRAIN) {
                     // register 4 g + e of sub-tile kt is key 32 kt + 8 g + 4 h + e of query q0 + i
-                    const size_t prow = ((size_t)(chunk * IEF_H + head) * IEF_T + (q0 + i)) * IEF_T + 4 * h;
-                    float* Pp = tx->P[mod] + prow;
-#pragma unroll
-                    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *(f32x4*)(Pp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
+                    __syncthreads();               // every wave is done with tile 3: its buffer is scratch now
+                    float* tl = (float*)(kvs + (3 & 1) * ATS_BUF) + wave * (32 * 68);
+                    const size_t wrow = ((size_t)(chunk * IEF_H + head) * IEF_T + __builtin_amdgcn_readfirstlane(q0)) * IEF_T;
+                    const int vrow = ((lane >> 4) * IEF_T + (lane & 15) * 4) * 4;
+                    const auto Pw = ATS_ROWS_RSRC(tx->P[mod]);
+                    ATS_PUT_ROWS(Pw)
                     if (tx->Pd[mod]) {           // uniform
                         const float pdrop = tx->drop_p[mod];
                         const float scale = (float)(1.0 / (1.0 - (double)pdrop));
                         const unsigned thr = (unsigned)((double)pdrop * 16777216.0);
                         const unsigned char* kp = tx->keep[mod];
                         const unsigned long long seed = tx->seed[mod];
-                        float* Dp = tx->Pd[mod] + prow;
+                        const size_t prow = wrow + (size_t)i * IEF_T + 4 * h;      // element index of this lane's first key
 #pragma unroll
                         for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -280,8 +315,9 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                                     const bool k = kp ? ((kb >> (8 * e)) & 0xffu) != 0 : dropout_bits(seed, idx0 + e) >= thr;
                                     st[kt][4 * g + e] = k ? st[kt][4 * g + e] * scale : 0.f;
                                 }
-                                *(f32x4*)(Dp + 32 * kt + 8 * g) = f32x4{st[kt][4 * g], st[kt][4 * g + 1], st[kt][4 * g + 2], st[kt][4 * g + 3]};
                             }
+                        const auto Dw = ATS_ROWS_RSRC(tx->Pd[mod]);
+                        ATS_PUT_ROWS(Dw)
                     }
                 }
             }
@@ -319,6 +355,10 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
     }
 #undef ATS_LOAD
 #undef ATS_WRITE
+#undef ATS_TL
+#undef ATS_PUT_ROWS
+#undef ATS_GET_ROWS
+#undef ATS_ROWS_RSRC
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
     if constexpr (BWD) {
         float* dq = tx->dQ[mod] + (size_t)row0 * (3 * IEF_D) + head * IEF_DH;
