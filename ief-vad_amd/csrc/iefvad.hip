@@ -223,6 +223,8 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_split_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_gemm_split_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES_OF(4));
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_pbf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APB_LDS_BYTES);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_attention_pbf16_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APB_LDS_BYTES);
@@ -230,6 +232,7 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, h->device);
         h->num_cus = e == hipSuccess ? prop.multiProcessorCount : 256;
+        g_num_cus = h->num_cus;
     }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_gemm_f32_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -188,15 +188,36 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
     if ((size_t)splits * per > part_floats) return fail("train_backward: split-K scratch too small");
     const int ms = rows / splits;
     if (split_tn && ms % TN_BK == 0 && n_out % 128 == 0 && (ldy & 3) == 0) {
-        // bf16x6 handles: the same partial products on the bf16 matrix pipe (gemm_split_tn.h), the same fixed-order reduction behind them
+        // bf16x6 handles: the same partial products on the bf16 matrix pipe (gemm_split_tn.h), the same fixed-order reduction behind them.
+        // Default: the 128 x 256 block (64 x 128 per wave, two workgroups per CU) over as many RAGGED row slices as fill the chip's
+        // workgroup slots once (at most the slices the scratch was sized for); IEFVAD_TN=128 keeps the 128 x 128 block over the
+        // power-of-two slices (A/B).
+        const char* tn_env = getenv("IEFVAD_TN");
+        const bool wide = !(tn_env && tn_env[0] == '1');
         TnArgs g;
         memset(&g, 0, sizeof(g));
-        g.A = dY; g.B = X; g.C = part; g.M = n_out; g.N = IEF_D; g.R = ms; g.lda = ldy; g.ldb = IEF_D; g.ldc = IEF_D; g.tiles_n = IEF_D / 128;
+        g.A = dY; g.B = X; g.C = part; g.M = n_out; g.N = IEF_D; g.lda = ldy; g.ldb = IEF_D; g.ldc = IEF_D;
+        g.nk_total = rows / TN_BK;
+        int slices = splits;
+        if (wide) {
+            const int tiles = (n_out / 128) * (IEF_D / 256);
+            slices = (2 * g_num_cus) / tiles;
+            if (slices > g.nk_total / 8) slices = g.nk_total / 8;
+            if (slices > splits) slices = splits;          // the scratch (part, cpart) holds `splits` partial results
+            if (slices < 1) slices = 1;
+        }
+        g.slices = slices;
+        g.tiles_n = wide ? IEF_D / 256 : IEF_D / 128;
         // the bias gradient of the same Linear (column sums of dY) rides along in the first column block's workgroups
-        const bool with_db = (db || db2) && cpart && db_done && (size_t)splits * n_out <= cpart_floats;
+        const bool with_db = (db || db2) && cpart && db_done && (size_t)slices * n_out <= cpart_floats;
         g.colsum = with_db ? cpart : nullptr;
-        hipLaunchKernelGGL(iefvad_gemm_split_tn_kernel, dim3((unsigned)((n_out / 128) * (IEF_D / 128) * splits)), dim3(256), TN_LDS_BYTES, stream, g);
+        if (wide)
+            hipLaunchKernelGGL(iefvad_gemm_split_tn256_kernel, dim3((unsigned)((n_out / 128) * g.tiles_n * slices)), dim3(256), TN_LDS_BYTES_OF(4), stream, g);
+        else
+            hipLaunchKernelGGL(iefvad_gemm_split_tn_kernel, dim3((unsigned)((n_out / 128) * g.tiles_n * slices)), dim3(256), TN_LDS_BYTES, stream, g);
         HIP_TRY(hipGetLastError());
+        const int splits_tn = slices;
+#define splits splits_tn
         if (dW) {
             const size_t n = (size_t)(n_split > 0 ? n_split : n_out) * IEF_D;
             hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part, per, splits, n, dW, alpha);
@@ -218,6 +239,7 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
             }
             *db_done = true;
         }
+#undef splits
         HIP_TRY(hipGetLastError());
         return 0;
     }
