@@ -216,30 +216,27 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
         else
             hipLaunchKernelGGL(iefvad_gemm_split_tn_kernel, dim3((unsigned)((n_out / 128) * g.tiles_n * slices)), dim3(256), TN_LDS_BYTES, stream, g);
         HIP_TRY(hipGetLastError());
-        const int splits_tn = slices;
-#define splits splits_tn
         if (dW) {
             const size_t n = (size_t)(n_split > 0 ? n_split : n_out) * IEF_D;
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part, per, splits, n, dW, alpha);
+            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part, per, slices, n, dW, alpha);
         }
         if (dW2) {
             const size_t n = (size_t)(n_out - n_split) * IEF_D;
             hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
-                               per, splits, n, dW2, alpha);
+                               per, slices, n, dW2, alpha);
         }
         if (with_db) {
             if (db) {
                 const size_t n = n_split > 0 ? n_split : n_out;
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart, (size_t)n_out, splits, n, db, alpha);
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart, (size_t)n_out, slices, n, db, alpha);
             }
             if (db2) {
                 const size_t n = n_out - n_split;
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart + n_split, (size_t)n_out, splits,
+                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart + n_split, (size_t)n_out, slices,
                                    n, db2, alpha);
             }
             *db_done = true;
         }
-#undef splits
         HIP_TRY(hipGetLastError());
         return 0;
     }
