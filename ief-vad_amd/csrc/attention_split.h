@@ -64,21 +64,24 @@ __device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, u32x4 (
 __device__ __forceinline__ int wave_id_of(int t) { return t >> 6; }
 
 // TRAIN (round 5, the train-mode forward of train.h): the same kernel, but the probabilities leave the chip -- autograd's backward needs
-// P = softmax(S) and Pd = dropout(P) ([chunks, 8, 256, 256] fp32 each; the backward products of backward.h read them) -- and q arrives
-// scaled by 1 / sqrt(96) only (the backward differentiates THAT scale), so the scores are multiplied by log2(e) inside the exp2.  In
-// the accumulator a lane holds one query's keys in groups of four consecutive ones: P and Pd go out as 16-byte stores.  The dropout
-// mask is the injected one (`keep`, one byte per element) or common.h's counter-based bits, element for element those of the
-// stand-alone softmax kernel.  Replaces three launches (S = q k^T on the fp32 MFMA kernel, softmax + dropout, Pd v) that wrote and
-// re-read S.
+// P = softmax(S) and Pd = dropout(P) -- and q arrives scaled by 1 / sqrt(96) only (the backward differentiates THAT scale), so the
+// scores are multiplied by log2(e) inside the exp2.  ONE [chunks, 8, 256, 256] fp32 tensor carries both: a probability is never
+// negative, so its sign bit is free and holds the dropout mask (set = dropped; -0.0 for a dropped zero).  P = |stored| and
+// Pd = sign ? 0 : stored / (1 - p) (dropped_from_signed below, the forward's own multiplication) are bit for bit what two tensors
+// held -- half the buffer, half the forward's stores and a third less to read in the backward.  The dropout mask is the injected one
+// (`keep`, one byte per element) or common.h's counter-based bits, element for element those of the stand-alone softmax kernel.
+// Replaces three launches (S = q k^T on the fp32 MFMA kernel, softmax + dropout, Pd v) that wrote and re-read S.
+// (dropped_from_signed / with_sign_bit: common.h)
 struct AttnTrainArgs {
-    float* P[2];                    // per modality
-    float* Pd[2];                   // nullable: no dropout (p == 0 and no injected mask), Pd is P
+    float* P[2];                    // per modality: the sign-carrying probabilities
+    int drop[2];                    // dropout in force (p > 0 or an injected mask): sign bits are written / interpreted
     const unsigned char* keep[2];   // nullable: injected masks, [chunks, 8, 256, 256] bytes (1 = keep)
     unsigned long long seed[2];
     float drop_p[2];
     // BWD (the first half of the same kernel with other operands: d Pd^T = v d att^T per (chunk, head), then the softmax backward on the
     // accumulators -- a lane holds a whole query row, so rowsum(Pd .* d Pd) is an in-lane sum and one shfl_xor):
-    // d S = Pd .* d Pd - P rowsum(Pd .* d Pd) leaves as fp32; replaces the d Pd product and the stand-alone softmax backward
+    // d S = Pd .* d Pd - P rowsum(Pd .* d Pd) leaves as fp32; replaces the d Pd product and the stand-alone softmax backward.  Both
+    // passes read the one sign-carrying tensor (the second finds it in the cache hierarchy)
     const float* dO[2];             // d att: [rows, 768], head h at columns 96 h
     float* dS[2];                   // [chunks, 8, 256, 256]
     // ... and the second half runs on d S where the forward runs on P: d q = q_scale d S k (the k rows staged where the forward stages
@@ -87,10 +90,11 @@ struct AttnTrainArgs {
     float q_scale;
 };
 
-// MODE 0: eval; 1: train-mode forward (TRAIN); 2: train-mode backward, d S (BWD)
+// MODE 0: eval; 1: train-mode forward (TRAIN); 2: train-mode backward, d S (BWD); 3: TRAIN with an injected mask (an instantiation of
+// its own: with both mask sources in one kernel hipcc spilled 56 registers around the softmax, the hash-only kernel none)
 template <bool F16, bool RG = false, int MODE = 0>
 __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t* kvs, const AttnTrainArgs* tx = nullptr) {
-    constexpr bool TRAIN = MODE == 1, BWD = MODE == 2;
+    constexpr bool TRAIN = MODE == 1 || MODE == 3, BWD = MODE == 2, INJECTED = MODE == 3;
     constexpr int NT = 8;                            // staged 64-key tiles: k then v (BWD: v, then k)
     constexpr int NP = F16 ? 2 : 3;
     // grid (8 heads, 2 query halves, chunks x modalities), see attention_f32.h
@@ -207,16 +211,17 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
 #define ATS_TL(row_, col_) (tl + (row_) * 68 + (col_))
             // registers (st) -> slice -> memory rows q0 .. q0 + 31 through descriptor `rs_` (based at row q0, key 0; 32 KB): the lane's
             // part of the address is ONE register (vrow), the rest scalar offsets -- 64-bit addresses per (row group, batch) cost 16 spills
-#define ATS_PUT_ROWS(rs_)                                                                                              \
-    _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) {                                                                 \
+#define ATS_PUT_ROWS_B(rs_, b4)                                                                                        \
+    {                                                                                                                  \
         _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                  \
             _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                              \
-                *(f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h) = f32x4{st[2 * b4 + u][4 * g], st[2 * b4 + u][4 * g + 1],   \
-                                                                   st[2 * b4 + u][4 * g + 2], st[2 * b4 + u][4 * g + 3]}; \
+                *(f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h) = f32x4{st[2 * (b4) + u][4 * g], st[2 * (b4) + u][4 * g + 1], \
+                                                                   st[2 * (b4) + u][4 * g + 2], st[2 * (b4) + u][4 * g + 3]}; \
         _Pragma("unroll") for (int sr = 0; sr < 8; ++sr)                                                               \
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)ATS_TL(4 * sr + (lane >> 4), (lane & 15) * 4)), \
-                                                   rs_, vrow, (4 * sr * IEF_T + 64 * b4) * 4, 0);                      \
+                                                   rs_, vrow, (4 * sr * IEF_T + 64 * (b4)) * 4, 0);                    \
     }
+#define ATS_PUT_ROWS(rs_) _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) ATS_PUT_ROWS_B(rs_, b4)
             // memory rows -> slice; afterwards ATS_TL(i, 32 u + 8 g + 4 h) is this lane's group g of sub-tile 2 b4 + u
 #define ATS_GET_ROWS(rs_, b4_)                                                                                         \
     _Pragma("unroll") for (int sr = 0; sr < 8; ++sr)                                                                   \
@@ -231,18 +236,21 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                 const size_t wrow = ((size_t)(chunk * IEF_H + head) * IEF_T + __builtin_amdgcn_readfirstlane(q0)) * IEF_T;
                 const int vrow = ((lane >> 4) * IEF_T + (lane & 15) * 4) * 4;
                 const auto Pw = ATS_ROWS_RSRC(tx->P[mod]);
-                const auto Dw = ATS_ROWS_RSRC(tx->Pd[mod]);     // the caller passes P when no dropout was in force
+                const float dscale = tx->drop[mod] ? (float)(1.0 / (1.0 - (double)tx->drop_p[mod])) : 1.0f;      // the forward's factor
                 float d = 0.f;
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) {
-                    ATS_GET_ROWS(Dw, b4)
+                    ATS_GET_ROWS(Pw, b4)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const f32x4 pd = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
+                            const f32x4 ps = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { st[2 * b4 + u][4 * g + e] *= pd[e]; d += st[2 * b4 + u][4 * g + e]; }
+                            for (int e = 0; e < 4; ++e) {
+                                st[2 * b4 + u][4 * g + e] *= dropped_from_signed(ps[e], dscale);
+                                d += st[2 * b4 + u][4 * g + e];
+                            }
                         }
                     __builtin_amdgcn_sched_barrier(0);      // one batch of loads ahead at most: hipcc otherwise hoists all four and spills
                 }
@@ -254,9 +262,9 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const f32x4 pv = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
+                            const f32x4 ps = *(const f32x4*)ATS_TL(i, 32 * u + 8 * g + 4 * h);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) st[2 * b4 + u][4 * g + e] -= pv[e] * d;      // d S stays in the registers: the A operand of d q = d S k
+                            for (int e = 0; e < 4; ++e) st[2 * b4 + u][4 * g + e] -= __builtin_fabsf(ps[e]) * d;      // d S stays in the registers: the A operand of d q = d S k
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -295,29 +303,45 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
                     const size_t wrow = ((size_t)(chunk * IEF_H + head) * IEF_T + __builtin_amdgcn_readfirstlane(q0)) * IEF_T;
                     const int vrow = ((lane >> 4) * IEF_T + (lane & 15) * 4) * 4;
                     const auto Pw = ATS_ROWS_RSRC(tx->P[mod]);
-                    ATS_PUT_ROWS(Pw)
-                    if (tx->Pd[mod]) {           // uniform
-                        const float pdrop = tx->drop_p[mod];
-                        const float scale = (float)(1.0 / (1.0 - (double)pdrop));
-                        const unsigned thr = (unsigned)((double)pdrop * 16777216.0);
+                    const bool drop = tx->drop[mod] != 0;      // uniform
+                    const float scale = (float)(1.0 / (1.0 - (double)tx->drop_p[mod]));
+                    if (drop) {
+                        // the mask goes into the sign bits (dropped = negative): dropped <=> mask byte 0 / 24 random bits < thr <=> the
+                        // difference below is negative, and its sign bit IS the flag (no compare, no lane mask to keep alive)
+                        const unsigned thr = (unsigned)((double)tx->drop_p[mod] * 16777216.0);
                         const unsigned char* kp = tx->keep[mod];
                         const unsigned long long seed = tx->seed[mod];
                         const size_t prow = wrow + (size_t)i * IEF_T + 4 * h;      // element index of this lane's first key
+                        if constexpr (INJECTED) {
+#pragma unroll
+                            for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const unsigned kb = *(const unsigned*)(kp + prow + 32 * kt + 8 * g);      // four mask bytes (the index is a multiple of 4)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        st[kt][4 * g + e] = with_sign_bit(st[kt][4 * g + e], (((kb >> (8 * e)) & 0xffu) - 1u) & 0x80000000u);
+                                    if (g == 3) __builtin_amdgcn_sched_barrier(0);      // four mask loads ahead at most (all 32: 48 spilled registers)
+                                }
+                        } else {
+#pragma unroll
+                            for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        st[kt][4 * g + e] = with_sign_bit(st[kt][4 * g + e],
+                                                                          (dropout_bits(seed, prow + 32 * kt + 8 * g + e) - thr) & 0x80000000u);
+                                __builtin_amdgcn_sched_barrier(0);      // sixteen hashes interleaved at most
+                            }
+                        }
+                    }
+                    ATS_PUT_ROWS(Pw)           // one copy of the store sequence for both cases
+                    if (drop) {                // Pd stays in the registers for P V
 #pragma unroll
                         for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const size_t idx0 = prow + 32 * kt + 8 * g;
-                                unsigned kb = 0;
-                                if (kp) kb = *(const unsigned*)(kp + idx0);      // four mask bytes (idx0 is a multiple of 4)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const bool k = kp ? ((kb >> (8 * e)) & 0xffu) != 0 : dropout_bits(seed, idx0 + e) >= thr;
-                                    st[kt][4 * g + e] = k ? st[kt][4 * g + e] * scale : 0.f;
-                                }
-                            }
-                        const auto Dw = ATS_ROWS_RSRC(tx->Pd[mod]);
-                        ATS_PUT_ROWS(Dw)
+                            for (int r = 0; r < 16; ++r) st[kt][r] = dropped_from_signed(st[kt][r], scale);
                     }
                 }
             }
@@ -357,6 +381,7 @@ __device__ __forceinline__ void attention_split_body(const AttnArgs args, bf16_t
 #undef ATS_WRITE
 #undef ATS_TL
 #undef ATS_PUT_ROWS
+#undef ATS_PUT_ROWS_B
 #undef ATS_GET_ROWS
 #undef ATS_ROWS_RSRC
     // store: accumulator col = d (lane & 31), row = query (r&3) + 8(r>>2) + 4h
@@ -399,13 +424,19 @@ __global__ __launch_bounds__(256, 2) void iefvad_attention_split_rows_kernel(Att
     attention_split_body<false, true>(args, kvs);
 }
 
-// train-mode forward: P and dropout(P) are stored (train.h)
+// train-mode forward: P is stored with the dropout mask in its sign bits (train.h)
 __global__ __launch_bounds__(256, 2) void iefvad_attention_split_train_kernel(AttnArgs args, AttnTrainArgs tx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
     attention_split_body<false, false, 1>(args, kvs, &tx);
 }
 
-// train-mode backward: d S from d att, v, P and dropout(P) (train.h)
+// the same with the caller's mask (tx.keep non-null for both modalities) instead of the generator's
+__global__ __launch_bounds__(256, 2) void iefvad_attention_split_train_mask_kernel(AttnArgs args, AttnTrainArgs tx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
+    attention_split_body<false, false, 3>(args, kvs, &tx);
+}
+
+// train-mode backward: d S from d att, v and the sign-carrying P (train.h)
 __global__ __launch_bounds__(256, 2) void iefvad_attention_split_ds_kernel(AttnArgs args, AttnTrainArgs tx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t kvs[];
     attention_split_body<false, false, 2>(args, kvs, &tx);

@@ -47,6 +47,9 @@ struct BgemmArgs {
     // epilogue extras (zero / null in every product of the backward pass): v = act(alpha * acc + bias[j] + R[i, j])
     const float* bias;       // nullable: [N], broadcast over the rows (and over the batch)
     int act;                 // 0 none; 1 QuickGELU v * sigmoid(1.702 v) (/root/reference/model/module.py:15-17); 2 ELU (layers.py:43-44)
+    // A holds the train forward's sign-carrying probabilities (attention_split.h): A(i, k) = sign ? 0 : stored * a_drop, i.e.
+    // dropout(P), formed between the tile's load and its LDS store; 0 = A is taken as it is
+    float a_drop;
 };
 
 #define BG_BM 128
@@ -116,6 +119,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
     f32x4 ra[TA::NV], rb[TB::NV];
     TA::load(Ab, a.lda, 0, ra, t);
     TB::load(Bb, a.ldb, 0, rb, t);
+    if (a.a_drop != 0.f) {
+#pragma unroll
+        for (int u = 0; u < TA::NV; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[u][e] = dropped_from_signed(ra[u][e], a.a_drop);
+    }
     TA::store(smem, ra, t);
     TB::store(smem + 2 * ASZ, rb, t);
     __syncthreads();
@@ -148,6 +157,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
             for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c][b], acc[b], 0, 0, 0);
         }
         if (more) {
+            if (a.a_drop != 0.f) {      // uniform
+#pragma unroll
+                for (int u = 0; u < TA::NV; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[u][e] = dropped_from_signed(ra[u][e], a.a_drop);
+            }
             TA::store(smem + (cur ^ 1) * ASZ, ra, t);
             TB::store(smem + 2 * ASZ + (cur ^ 1) * BSZ, rb, t);
         }

@@ -119,6 +119,17 @@ __device__ __forceinline__ int amax_exponent(float amax) {
     return e - 127 < IEF_AMAX_EXP_CAP ? e - 127 : IEF_AMAX_EXP_CAP;
 }
 
+// The train forward's sign-carrying attention probabilities (attention_split.h TRAIN): stored = P with the sign bit set where the
+// element was dropped.  Both helpers take the value BY VALUE on purpose: __builtin_bit_cast applied directly to an element of an
+// ext_vector_type (st[kt][r]) read element 0 of the vector for every r (hipcc 7.2: the OR below then mixed st[kt][0] into all sixteen
+// elements of a sub-tile -- found by comparing the stored tensor with softmax(q k^T)).
+__device__ __forceinline__ float dropped_from_signed(float ps, float scale) {      // dropout(P) = sign ? 0 : P / (1 - p)
+    return __builtin_bit_cast(int, ps) < 0 ? 0.f : ps * scale;
+}
+__device__ __forceinline__ float with_sign_bit(float x, unsigned signbit) {         // signbit: 0 or 0x80000000
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) | signbit);
+}
+
 // Counter-based uniform bits for the attention-dropout mask (train mode): a 32-bit mix (murmur3's finaliser, twice) of (seed, element
 // index); the same (seed, index) always gives the same bits, so nothing but the seed has to be remembered, and the fused attention
 // kernel (attention_split.h, TRAIN) and the stand-alone softmax kernel (backward.h) draw the same mask.  torch draws its mask from

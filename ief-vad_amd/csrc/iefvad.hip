@@ -253,6 +253,9 @@ extern "C" int iefvad_create(const iefvad_config* cfg, iefvad_handle** out) {
         e = hipFuncSetAttribute((const void*)iefvad_attention_split_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ATS_LDS_BYTES);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)iefvad_attention_split_train_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ATS_LDS_BYTES);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)iefvad_heads_chain_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HC_LDS_BYTES);
     if (e == hipSuccess)

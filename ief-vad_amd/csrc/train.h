@@ -6,7 +6,8 @@
 //   iefvad_train_forward   the forward of imf_vad.py:109-161 in train mode (attention dropout, imf_vad.py:70) that KEEPS what the
 //                          backward needs, in a caller-owned buffer:
 //                            per modality and layer: the layer input x_l, q | k | v (q pre-scaled by 1 / sqrt(96)), the attention
-//                            probabilities P (and their dropped copy), the attention output, the pre-LayerNorm sum;
+//                            probabilities P (bf16x6: ONE tensor, the dropout mask in its sign bits -- attention_split.h; f32:
+//                            P and its dropped copy), the attention output, the pre-LayerNorm sum;
 //                            the last LayerNorm output, the whitened rows, mu and logvar of both modalities;
 //                            the refinement states z_0 .. z_K and hidden activations h_0 .. h_{K-1}
 //   iefvad_train_backward  the gradients of every parameter, given the gradients of the eight outputs
@@ -40,7 +41,15 @@ static int splitk_splits(int rows, int n_out) {
     return s;
 }
 
-static TrainLayout train_layout(int L, int K, int B) {
+// The fused train-mode attention launches (bf16x6; attention_split.h TRAIN / BWD) keep P and dropout(P) as ONE sign-carrying tensor;
+// the three-launch path (f32 arithmetic, or IEFVAD_TRAIN_ATTN=unfused for the A/B test) keeps two.  The switch is read when a buffer
+// is sized and when a forward starts; the backward follows its forward's record.
+static bool train_attn_fused(const iefvad_handle* h) {
+    const char* v = getenv("IEFVAD_TRAIN_ATTN");
+    return h->cfg.compute == IEFVAD_COMPUTE_BF16X6 && !(v && v[0] == 'u');
+}
+
+static TrainLayout train_layout(int L, int K, int B, bool signed_p) {
     TrainLayout t;
     memset(&t, 0, sizeof(t));
     const size_t rows = (size_t)B * IEF_T;
@@ -55,7 +64,7 @@ static TrainLayout train_layout(int L, int K, int B) {
             t.att[m][l] = take(t.U);
             t.s[m][l] = take(t.U);
             t.P[m][l] = take(t.PU);
-            t.Pd[m][l] = take(t.PU);
+            t.Pd[m][l] = signed_p ? t.P[m][l] : take(t.PU);
         }
         t.E[m] = take(t.U);
         t.mu[m] = take(t.U);
@@ -66,12 +75,25 @@ static TrainLayout train_layout(int L, int K, int B) {
     t.logits = take(rows);
     t.g = take(t.U);
     t.da = take(t.U);
-    t.dh[0] = take(2 * t.U);
-    t.dh[1] = take(2 * t.U);
-    t.gx = take(t.U);
-    t.datt = take(t.U);
-    t.dqkv = take(3 * t.U);
-    t.dP = take(t.PU);
+    // Scratch of the backward's second half (fusion, heads, encoder layers).  By then the refinement steps have been differentiated and
+    // their saved states z_0 .. z_K, h_0 .. h_{K-1} -- (2K + 1) U contiguous floats -- are dead: the scratch tensors live THERE as far as
+    // they fit (all of them from K = 6 on), largest first.  The backward therefore consumes the buffer: one backward per forward
+    // (iefvad_train_backward retires the forward's record).
+    {
+        size_t dead = t.z[0];
+        const size_t dead_end = t.z[0] + (size_t)(2 * K + 1) * t.U;
+        auto place = [&](size_t n) {
+            const size_t n64 = (n + 63) & ~(size_t)63;
+            if (dead + n64 <= dead_end) { const size_t r = dead; dead += n64; return r; }
+            return take(n);
+        };
+        t.dqkv = place(3 * t.U);
+        t.dP = place(t.PU);
+        t.dh[0] = place(2 * t.U);
+        t.dh[1] = place(2 * t.U);
+        t.gx = place(t.U);
+        t.datt = place(t.U);
+    }
     size_t pf = 0;
     const int nouts[3] = {IEF_D, 2 * IEF_D, 3 * IEF_D};
     for (int n : nouts) {
@@ -90,7 +112,7 @@ static TrainLayout train_layout(int L, int K, int B) {
 
 extern "C" size_t iefvad_train_workspace_bytes(const iefvad_handle* h, int32_t B) {
     if (!h || B <= 0 || B > 4096) return 0;
-    return train_layout(h->cfg.num_layers, h->cfg.num_steps, B).total * sizeof(float) + 256;
+    return train_layout(h->cfg.num_layers, h->cfg.num_steps, B, train_attn_fused(h)).total * sizeof(float) + 256;
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------------------------------------------
@@ -280,7 +302,7 @@ static int launch_db(const float* Y, int ld, int ncols, float* db, float* db2, i
 
 // What a train-mode forward leaves on the handle for its backward: which buffer it filled, at which batch size, and whether the
 // dropped copy of the probabilities exists.  A handful of forwards may be outstanding (one record per training buffer).
-struct TrainRecord { const void* ws; int B; bool drop[2][IEFVAD_MAX_LAYERS]; unsigned long long stamp; };
+struct TrainRecord { const void* ws; int B; bool drop[2][IEFVAD_MAX_LAYERS]; float drop_p[2][IEFVAD_MAX_LAYERS]; bool fused; unsigned long long stamp; };
 struct TrainState { TrainRecord rec[8]; unsigned long long clock = 0; };
 
 static void release_train(iefvad_handle* h) {
@@ -288,14 +310,15 @@ static void release_train(iefvad_handle* h) {
     h->train = nullptr;
 }
 
-static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t ws_bytes, const char* who) {
+static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t ws_bytes, const char* who, int fused = -1) {
     if (!h) return fail("%s: null handle", who);
     if (!h->weights_set) return fail("%s: weights not set", who);
     if (h->cfg.compute != IEFVAD_COMPUTE_F32 && h->cfg.compute != IEFVAD_COMPUTE_BF16X6)
         return fail("%s: training runs in the fp32-accurate arithmetics only (compute f32 or bf16x6)", who);
     if (B <= 0 || B > 4096) return fail("%s: B = %d outside 1..4096", who, B);
-    if (!ws || ws_bytes < iefvad_train_workspace_bytes(h, B))
-        return fail("%s: training buffer too small (%zu < %zu bytes)", who, ws_bytes, iefvad_train_workspace_bytes(h, B));
+    const size_t need = fused < 0 ? iefvad_train_workspace_bytes(h, B)
+                                  : train_layout(h->cfg.num_layers, h->cfg.num_steps, B, fused != 0).total * sizeof(float) + 256;
+    if (!ws || ws_bytes < need) return fail("%s: training buffer too small (%zu < %zu bytes)", who, ws_bytes, need);
     if ((uintptr_t)ws & 255) return fail("%s: the training buffer must be 256-byte aligned", who);
     return 0;
 }
@@ -304,7 +327,9 @@ static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t
 extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
                                     const iefvad_train_options* opt, void* train_ws, size_t train_ws_bytes, const iefvad_outputs* out,
                                     void* stream_) {
-    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_forward")) return rc;
+    if (!h) return fail("iefvad_train_forward: null handle");
+    const bool fused = train_attn_fused(h);
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_forward", fused)) return rc;
     if (!img || !ev || !out || !opt) return fail("iefvad_train_forward: null argument");
     if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
         return fail("iefvad_train_forward: unknown in_dtype %d", in_dtype);
@@ -316,7 +341,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             if (!(opt->dropout_p[m][l] >= 0.f && opt->dropout_p[m][l] < 1.f))
                 return fail("iefvad_train_forward: dropout_p[%d][%d] = %g outside [0, 1)", m, l, (double)opt->dropout_p[m][l]);
     hipStream_t stream = (hipStream_t)stream_;
-    const TrainLayout t = train_layout(L, K, B);
+    const TrainLayout t = train_layout(L, K, B, fused);
     float* ws = (float*)train_ws;
     const int rows = B * IEF_T;
     Timer tm;
@@ -333,9 +358,12 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             if (ts.rec[i].stamp < ts.rec[slot].stamp) slot = i;
         }
         TrainRecord& r = ts.rec[slot];
-        r.ws = train_ws; r.B = B; r.stamp = ++ts.clock;
+        r.ws = train_ws; r.B = B; r.fused = fused; r.stamp = ++ts.clock;
         for (int m = 0; m < 2; ++m)
-            for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) r.drop[m][l] = l < L && (opt->dropout_p[m][l] > 0.f || opt->keep_mask);
+            for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) {
+                r.drop[m][l] = l < L && (opt->dropout_p[m][l] > 0.f || opt->keep_mask);
+                r.drop_p[m][l] = l < L ? opt->dropout_p[m][l] : 0.f;
+            }
     }
     const bool splitmb = c.compute == IEFVAD_COMPUTE_BF16X6 && split_eligible(rows, IEF_D, IEF_D, 1);
     const float qscale = 1.0f / sqrtf((float)IEF_DH);
@@ -364,11 +392,9 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
 
         // bf16x6: S = q k^T -> softmax -> dropout -> Pd v in ONE launch for both modalities (attention_split.h, TRAIN: the eval kernel
-        // with P and Pd stored for the backward); IEFVAD_TRAIN_ATTN=unfused keeps the three launches below (A/B).  The fp32 arithmetic
-        // keeps them: its products stay on the fp32 MFMA instruction.
-        const char* attn_env = getenv("IEFVAD_TRAIN_ATTN");      // read per call: the A/B test flips it between two forwards
-        const bool attn_unfused = attn_env && attn_env[0] == 'u';
-        if (c.compute == IEFVAD_COMPUTE_BF16X6 && !attn_unfused) {
+        // with the sign-carrying P stored for the backward); IEFVAD_TRAIN_ATTN=unfused keeps the three launches below (A/B: read per
+        // call, the test flips it between two forwards).  The fp32 arithmetic keeps them: its products stay on the fp32 MFMA instruction.
+        if (fused) {
             AttnArgs aa;
             AttnTrainArgs tx;
             memset(&aa, 0, sizeof(aa));
@@ -380,12 +406,15 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
                 aa.qkv[m] = ws + t.qkv[m][l];
                 aa.out[m] = ws + t.att[m][l];
                 tx.P[m] = ws + t.P[m][l];
-                tx.Pd[m] = drop ? ws + t.Pd[m][l] : nullptr;
+                tx.drop[m] = drop ? 1 : 0;
                 tx.keep[m] = opt->keep_mask ? opt->keep_mask + ((size_t)m * L + l) * t.PU : nullptr;
                 tx.seed[m] = opt->seed * 0x100000001B3ull + (unsigned long long)(m * IEFVAD_MAX_LAYERS + l + 1) * 0x9E3779B97F4A7C15ull;
                 tx.drop_p[m] = pdrop;
             }
-            hipLaunchKernelGGL(iefvad_attention_split_train_kernel, dim3(IEF_H, 2, 2 * B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
+            if (opt->keep_mask)
+                hipLaunchKernelGGL(iefvad_attention_split_train_mask_kernel, dim3(IEF_H, 2, 2 * B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
+            else
+                hipLaunchKernelGGL(iefvad_attention_split_train_kernel, dim3(IEF_H, 2, 2 * B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
             HIP_TRY(hipGetLastError());
         } else
         for (int m = 0; m < 2; ++m) {
@@ -492,17 +521,18 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
 // ---- backward -------------------------------------------------------------------------------------------------------------------------
 extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws, size_t train_ws_bytes, const iefvad_output_grads* dout,
                                      const iefvad_weight_grads* dw, void* stream_) {
-    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_backward")) return rc;
+    if (!h) return fail("iefvad_train_backward: null handle");
     if (!dout || !dw) return fail("iefvad_train_backward: null argument");
     const TrainRecord* rec = nullptr;
     if (h->train)
         for (int i = 0; i < 8; ++i)
             if (h->train->rec[i].ws == train_ws && h->train->rec[i].stamp) rec = &h->train->rec[i];
     if (!rec || rec->B != B) return fail("iefvad_train_backward: no iefvad_train_forward with B = %d has filled this training buffer", B);
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_backward", rec->fused)) return rc;
     const iefvad_config& c = h->cfg;
     const int L = c.num_layers, K = c.num_steps;
     hipStream_t stream = (hipStream_t)stream_;
-    const TrainLayout t = train_layout(L, K, B);
+    const TrainLayout t = train_layout(L, K, B, rec->fused);
     float* ws = (float*)train_ws;
     const int rows = B * IEF_T;
     const int nblk = (rows + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK;
@@ -592,8 +622,11 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             float* dP = ws + t.dP;
             const float* qkv = ws + t.qkv[m][l];
             const float* P = ws + t.P[m][l];
-            // Pd is P when neither a dropout probability nor a mask was in force in the forward
+            // Pd is P when neither a dropout probability nor a mask was in force in the forward; after a fused forward P carries the mask
+            // in its sign bits and Pd is formed from it where it is read (the d S launch, the A operand of d v)
             const float* Pd = rec->drop[m][l] ? ws + t.Pd[m][l] : P;
+            const bool signed_p = rec->fused && rec->drop[m][l];
+            const float drop_scale = (float)(1.0 / (1.0 - (double)rec->drop_p[m][l]));
             { bool db_done = false;
             if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->out_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
             if (!db_done)
@@ -603,10 +636,9 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
                             sA = (long long)IEF_T * IEF_D;
             BgemmArgs a;
             // bf16x6: d S = Pd .* d Pd - P rowsum(Pd .* d Pd) with d Pd = d att v^T in ONE launch (attention_split.h, BWD: the product on the
-            // split arithmetic, the softmax backward on its accumulators); IEFVAD_TRAIN_ATTN=unfused keeps the product on the fp32 MFMA
-            // kernel and the stand-alone softmax backward (A/B)
-            const char* attn_env = getenv("IEFVAD_TRAIN_ATTN");
-            const bool ds_fused = h->cfg.compute == IEFVAD_COMPUTE_BF16X6 && !(attn_env && attn_env[0] == 'u');
+            // split arithmetic, the softmax backward on its accumulators); after an IEFVAD_TRAIN_ATTN=unfused forward the product stays on
+            // the fp32 MFMA kernel with the stand-alone softmax backward (A/B)
+            const bool ds_fused = rec->fused;
             if (ds_fused) {
                 AttnArgs aa;
                 AttnTrainArgs tx;
@@ -614,7 +646,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
                 memset(&tx, 0, sizeof(tx));
                 aa.nchunks = B;
                 aa.qkv[0] = qkv;
-                tx.dO[0] = datt; tx.P[0] = const_cast<float*>(P); tx.Pd[0] = const_cast<float*>(Pd); tx.dS[0] = dP;
+                tx.dO[0] = datt; tx.P[0] = const_cast<float*>(P); tx.drop[0] = signed_p ? 1 : 0; tx.drop_p[0] = rec->drop_p[m][l]; tx.dS[0] = dP;
                 tx.dQ[0] = dqkv; tx.q_scale = qscale;
                 hipLaunchKernelGGL(iefvad_attention_split_ds_kernel, dim3(IEF_H, 2, B), dim3(256), ATS_LDS_BYTES, stream, aa, tx);
                 HIP_TRY(hipGetLastError());
@@ -631,6 +663,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             a.A = Pd; a.B = datt; a.C = dqkv + 2 * IEF_D;
             a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = IEF_D; a.ldc = 3 * IEF_D;
             a.a1 = sP1; a.a2 = sP2; a.b1 = sA; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
+            if (signed_p) a.a_drop = drop_scale;
             if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
             // d S = Pd .* d Pd - P rowsum(Pd .* d Pd)
             if (!ds_fused) {
@@ -662,5 +695,6 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
                 if (int rc = launch_dx(h, tp ? h->in_wst[m][l] : nullptr, dqkv, 3 * IEF_D, h->in_w[m][l], 3 * IEF_D, IEF_D, gx, gx, nullptr, 1.f, rows, stream)) return rc;
         }
     }
+    const_cast<TrainRecord*>(rec)->stamp = 0;      // the scratch tensors have overwritten the saved refinement states
     return 0;
 }

@@ -245,7 +245,9 @@ int iefvad_loss_backward(const float* logits, const float* image_mu, const float
  * iefvad_train_forward computes the eight outputs like iefvad_forward and keeps what the backward needs in `train_ws`
  * (iefvad_train_workspace_bytes; 256-byte aligned; owned by the caller, who keeps it untouched until the matching
  * iefvad_train_backward has run on the same stream).  compute must be IEFVAD_COMPUTE_F32 or IEFVAD_COMPUTE_BF16X6 (fp32-accurate);
- * the whole batch runs as one pass (B <= 4096).
+ * the whole batch runs as one pass (B <= 4096).  ONE backward per forward: the backward's scratch tensors overwrite saved states
+ * it has already differentiated, so a second iefvad_train_backward on the same buffer fails ("no iefvad_train_forward ...") until a
+ * new forward has filled it.
  *   dropout_p[m][l]  the probability nn.MultiheadAttention m / layer l drops an attention weight with (0 = none); kept weights
  *                    are scaled by 1 / (1 - p) as torch.nn.functional.dropout does
  *   seed             stream of the library's counter-based mask generator for this step.  torch draws its mask from its own Philox
