@@ -186,23 +186,6 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
         }
 }
 
-// dst[c][r] = src[r][c] (32 x 32 tiles through LDS): W^T for the transposed split planes of the bf16x6 backward (train.h)
-__global__ __launch_bounds__(256) void iefvad_transpose_f32_kernel(const float* src, float* dst, int rows, int cols) {
-    __shared__ float tile[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = r0 + ty + 8 * k, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------------
 // attention probabilities, train mode
 // ------------------------------------------------------------------------------------------------------------------------
@@ -292,10 +275,10 @@ __global__ __launch_bounds__(256) void iefvad_colsum_kernel(const float* Y, int 
 // are added in group order through LDS.  One workgroup per 64-element strip: a 1024-partial LayerNorm reduction is 64 dependent
 // steps per thread instead of 1024, a 32-way split-K reduction streams with every thread loading.
 #define RED_STRIP 64
-__global__ __launch_bounds__(256) void iefvad_reduce_parts_kernel(const float* part, size_t stride, int nparts, size_t n, float* out, float alpha) {
-    __shared__ __attribute__((aligned(16))) float sm[16][RED_STRIP];
+__device__ __forceinline__ void reduce_parts_strip(const float* part, size_t stride, int nparts, size_t n, float* out, float alpha, unsigned blk,
+                                                   float (*sm)[RED_STRIP]) {
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * RED_STRIP + 4 * c;
+    const size_t i = (size_t)blk * RED_STRIP + 4 * c;
     const int chunk = (nparts + 15) / 16;
     const int p0 = g * chunk, p1 = (p0 + chunk < nparts) ? p0 + chunk : nparts;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -318,7 +301,7 @@ __global__ __launch_bounds__(256) void iefvad_reduce_parts_kernel(const float* p
     *(f32x4*)&sm[g][4 * c] = s;
     __syncthreads();
     if (threadIdx.x < RED_STRIP) {
-        const size_t j = (size_t)blockIdx.x * RED_STRIP + threadIdx.x;
+        const size_t j = (size_t)blk * RED_STRIP + threadIdx.x;
         if (j < n) {
             float r = 0.f;
 #pragma unroll
@@ -326,6 +309,25 @@ __global__ __launch_bounds__(256) void iefvad_reduce_parts_kernel(const float* p
             out[j] = alpha * r;
         }
     }
+}
+__global__ __launch_bounds__(256) void iefvad_reduce_parts_kernel(const float* part, size_t stride, int nparts, size_t n, float* out, float alpha) {
+    __shared__ __attribute__((aligned(16))) float sm[16][RED_STRIP];
+    reduce_parts_strip(part, stride, nparts, n, out, alpha, blockIdx.x, sm);
+}
+
+// Up to four such reductions in ONE launch (the weight gradient of a Linear, its second half when two parameters share a product
+// -- the stacked mu | logvar heads -- and the bias gradient(s) of the same Linear; gamma and beta of a LayerNorm): job j owns
+// workgroups [first[j], first[j + 1]).  Same arithmetic, same order: same bits as four launches of the kernel above.
+struct ReduceJobs {
+    const float* part[4]; size_t stride[4]; int nparts[4]; size_t n[4]; float* out[4]; float alpha[4];
+    unsigned first[5];
+    int count;
+};
+__global__ __launch_bounds__(256) void iefvad_reduce_parts_multi_kernel(ReduceJobs a) {
+    __shared__ __attribute__((aligned(16))) float sm[16][RED_STRIP];
+    int j = 0;
+    while (j + 1 < a.count && blockIdx.x >= a.first[j + 1]) ++j;
+    reduce_parts_strip(a.part[j], a.stride[j], a.nparts[j], a.n[j], a.out[j], a.alpha[j], blockIdx.x - a.first[j], sm);
 }
 
 // the 4 waves' per-lane column partials (lane l owns columns 4 l + 256 j) -> part[block][768], waves added in order

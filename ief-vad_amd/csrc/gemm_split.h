@@ -119,6 +119,69 @@ __global__ __launch_bounds__(256) void iefvad_split_planes_kernel(const float* _
     }
 }
 
+// The same for up to SPLIT_MANY_MAX matrices in ONE launch (blockIdx.y = matrix): a training step changes every weight, so every
+// step re-splits all 10 + 2 K projection matrices and, for the backward's dX products, their transposes -- 90 launches of 5 us (the
+// stand-alone split, a transpose into scratch, the split of the scratch) were 0.46 ms of kernel time plus their launch gaps in a 27 ms
+// step.  `rows` = 0: planes of the matrix as it is (n elements); rows = n_out > 0: planes of the TRANSPOSE of W [n_out, 768], i.e. of
+// W^T [768, n_out] (64 x 32 tiles through LDS; a thread splits two neighbouring elements of a W^T row and stores one dword per plane).
+// Bit for bit the planes of iefvad_split_planes_kernel (the same v_cvt_pk_bf16_f32 / exact remainders).
+#define SPLIT_MANY_MAX 32
+struct SplitManyArgs {
+    const float* src[SPLIT_MANY_MAX];
+    bf16_t* dst[SPLIT_MANY_MAX];
+    unsigned n[SPLIT_MANY_MAX];          // elements per matrix (a multiple of 4; transposed: of 64 x 32)
+    int rows[SPLIT_MANY_MAX];
+    int count;
+};
+__global__ __launch_bounds__(256) void iefvad_split_planes_many_kernel(SplitManyArgs a) {
+    const int z = blockIdx.y;
+    const float* __restrict__ src = a.src[z];
+    bf16_t* __restrict__ planes = a.dst[z];
+    const size_t n = a.n[z];
+    const int n_out = a.rows[z];
+    if (n_out == 0) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+        for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+            Split4 s;
+            s.r = *(const f32x4*)(src + i);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                unsigned d0, d1;
+                s.plane(d0, d1, p < 2);
+                *(uint2*)(planes + (size_t)p * n + i) = make_uint2(d0, d1);
+            }
+        }
+        return;
+    }
+    // W [n_out, 768] -> W^T [768, n_out]: tile = 64 rows of W (r) x 32 columns (c); out element (c, r)
+    __shared__ float tile[64][33];
+    const int ncols = (int)(n / (size_t)n_out);       // 768
+    const int tr = n_out / 64, tc = ncols / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+        const int r0 = (t / tc) * 64, c0 = (t % tc) * 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[ty + 8 * k][tx] = src[(size_t)(r0 + ty + 8 * k) * ncols + c0 + tx];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = ty + 8 * k;                  // row of W^T inside the tile; this thread: elements r0 + 2 tx, r0 + 2 tx + 1
+            float x0 = tile[2 * tx][c], x1 = tile[2 * tx + 1][c];
+            const size_t o = (size_t)(c0 + c) * n_out + r0 + 2 * tx;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned d = cvt_pk_bf16(x0, x1);
+                *(unsigned*)(planes + (size_t)p * n + o) = d;
+                if (p < 2) {
+                    x0 -= __builtin_bit_cast(float, d << 16);
+                    x1 -= __builtin_bit_cast(float, d & 0xffff0000u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // F16 = false: three bf16 terms per operand, six products (the production arithmetic).
 // F16 = true (compute = fp16x3, opt-in): two fp16 terms per operand (22 bits), three products h1 g1 + h1 g2 + h2 g1 --
 // half the MFMAs; products good to ~2^-20.4 |a w| worst case (2^-23 typical).  fp16 has a 5-bit exponent, so both operands are scaled by powers of two (exact):

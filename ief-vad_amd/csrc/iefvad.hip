@@ -127,7 +127,7 @@ struct iefvad_handle {
     int num_cus;                // compute units of the device: grid size of the persistent row-block kernels
     // training in the bf16x6 arithmetic: three-plane splits of the TRANSPOSED projection matrices ([3][768][n_out]: dX = dY W as an NT
     // product on the split kernel), rebuilt by the first train-mode forward after every iefvad_set_weights (train.h)
-    bf16_t* arena_st; float* tscratch; float* zero_bias; bool tplanes_valid;
+    bf16_t* arena_st; float* zero_bias; bool tplanes_valid;
     bf16_t* in_wst[2][IEFVAD_MAX_LAYERS]; bf16_t* out_wst[2][IEFVAD_MAX_LAYERS]; bf16_t* head_wst[2];
     bf16_t* ref_w1st[IEFVAD_MAX_STEPS]; bf16_t* ref_w2st[IEFVAD_MAX_STEPS];
     struct HostPipe* hostpipe;  // staging slots, copy stream and workspace of iefvad_forward_videos_host (hostpipe.h)
@@ -299,7 +299,6 @@ extern "C" void iefvad_destroy(iefvad_handle* h) {
         }
     if (h->arena_s) (void)hipFree(h->arena_s);
     if (h->arena_st) (void)hipFree(h->arena_st);
-    if (h->tscratch) (void)hipFree(h->tscratch);
     if (h->zero_bias) (void)hipFree(h->zero_bias);
     if (h->arena_h) (void)hipFree(h->arena_h);
     if (h->amax_dev) (void)hipFree(h->amax_dev);
@@ -340,6 +339,40 @@ static int launch_split_planes(const float* src, bf16_t* planes, size_t n, hipSt
     hipLaunchKernelGGL(iefvad_split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, planes, n);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// batches of iefvad_split_planes_many_kernel launches (gemm_split.h): add() queues a matrix, flush() launches what is queued
+struct SplitMany {
+    SplitManyArgs a;
+    hipStream_t stream;
+    explicit SplitMany(hipStream_t s) : stream(s) { a.count = 0; }
+    int flush() {
+        if (a.count == 0) return 0;
+        hipLaunchKernelGGL(iefvad_split_planes_many_kernel, dim3(96, a.count), dim3(256), 0, stream, a);
+        a.count = 0;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // rows = 0: planes of src [n]; rows = n_out: planes of the transpose of src [n_out, n / n_out]
+    int add(const float* src, bf16_t* dst, size_t n, int rows) {
+        if (n % 4 || n > 0xffffffffu) return fail("split_bf16x3: n = %zu is not a multiple of 4 below 2^32", n);
+        if (rows && (rows % 64 || (n / rows) % 32 || n % rows)) return fail("split_bf16x3: transposed split of a [%d, %zu] matrix", rows, n / rows);
+        a.src[a.count] = src; a.dst[a.count] = dst; a.n[a.count] = (unsigned)n; a.rows[a.count] = rows;
+        if (++a.count == SPLIT_MANY_MAX) return flush();
+        return 0;
+    }
+};
+
+extern "C" int iefvad_split_bf16x3_many(const float* const* src, void* const* planes, const size_t* n, const int32_t* rows, int32_t count,
+                                        void* stream) {
+    if (!src || !planes || !n || !rows || count < 0) return fail("iefvad_split_bf16x3_many: null argument");
+    SplitMany sm((hipStream_t)stream);
+    for (int i = 0; i < count; ++i) {
+        if (!src[i] || !planes[i] || rows[i] < 0) return fail("iefvad_split_bf16x3_many: entry %d is null or has negative rows", i);
+        if (((uintptr_t)src[i] | (uintptr_t)planes[i]) & 15) return fail("iefvad_split_bf16x3_many: entry %d is not 16-byte aligned", i);
+        if (int rc = sm.add(src[i], (bf16_t*)planes[i], n[i], rows[i])) return rc;
+    }
+    return sm.flush();
 }
 
 extern "C" int iefvad_split_bf16x3(const float* src, void* planes, size_t n, void* stream) {
@@ -498,10 +531,11 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
         const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
         if (!h->arena_s) HIP_TRY(hipMalloc((void**)&h->arena_s, 3 * nb * sizeof(bf16_t)));
         bf16_t* q = h->arena_s;
+        SplitMany sm(stream);                 // all 10 + 2 K matrices in one launch (two from K = 12 on)
         auto split = [&](bf16_t** dst, const float* src, size_t n) -> int {
             *dst = q;
             q += 3 * n;
-            return launch_split_planes(src, *dst, n, stream);
+            return sm.add(src, *dst, n, 0);
         };
         for (int m = 0; m < 2; ++m) {
             for (int l = 0; l < L; ++l) {
@@ -514,6 +548,7 @@ extern "C" int iefvad_set_weights(iefvad_handle* h, const iefvad_weights* w, voi
             if (int rc = split(&h->ref_w1s[k], h->ref_w1[k], DD)) return rc;
             if (int rc = split(&h->ref_w2s[k], h->ref_w2[k], DD)) return rc;
         }
+        if (int rc = sm.flush()) return rc;
     }
     if (h->cfg.compute == IEFVAD_COMPUTE_FP16X3) {
         // two fp16 planes per projection matrix, scaled by a power of two from the matrix's max |w| (gemm_split.h, F16)

@@ -147,18 +147,16 @@ static int ensure_train_planes(iefvad_handle* h, hipStream_t stream) {
     const size_t D = IEF_D, DD = D * D;
     const size_t nb = 2 * (size_t)L * (3 * DD + DD) + 2 * (2 * DD) + (size_t)K * 2 * DD;
     if (!h->arena_st) HIP_TRY(hipMalloc((void**)&h->arena_st, 3 * nb * sizeof(bf16_t)));
-    if (!h->tscratch) HIP_TRY(hipMalloc((void**)&h->tscratch, 3 * DD * sizeof(float)));
     if (!h->zero_bias) {
         HIP_TRY(hipMalloc((void**)&h->zero_bias, 3 * D * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->zero_bias, 0, 3 * D * sizeof(float), stream));
     }
     bf16_t* q = h->arena_st;
+    SplitMany sm(stream);                     // one launch for all of them (gemm_split.h: transpose and split in one pass)
     auto tsplit = [&](bf16_t** dst, const float* W, int n_out) -> int {      // W [n_out, 768] -> planes of W^T [768, n_out]
         *dst = q;
         q += 3 * (size_t)n_out * D;
-        hipLaunchKernelGGL(iefvad_transpose_f32_kernel, dim3(IEF_D / 32, n_out / 32), dim3(256), 0, stream, W, h->tscratch, n_out, IEF_D);
-        HIP_TRY(hipGetLastError());
-        return launch_split_planes(h->tscratch, *dst, (size_t)n_out * D, stream);
+        return sm.add(W, *dst, (size_t)n_out * D, n_out);
     };
     for (int m = 0; m < 2; ++m) {
         for (int l = 0; l < L; ++l) {
@@ -171,6 +169,7 @@ static int ensure_train_planes(iefvad_handle* h, hipStream_t stream) {
         if (int rc = tsplit(&h->ref_w1st[k], h->ref_w1[k], IEF_D)) return rc;
         if (int rc = tsplit(&h->ref_w2st[k], h->ref_w2[k], IEF_D)) return rc;
     }
+    if (int rc = sm.flush()) return rc;
     h->tplanes_valid = true;
     return 0;
 }
@@ -197,6 +196,22 @@ static int launch_dx(iefvad_handle* h, const bf16_t* planes_t, const float* dY, 
     (void)h;
     return launch_bgemm(a, true, false, 1, stream);
 }
+
+// a batch of fixed-order reductions for one launch of iefvad_reduce_parts_multi_kernel (null destinations are skipped)
+struct ReduceBatch {
+    ReduceJobs j;
+    ReduceBatch() { memset(&j, 0, sizeof(j)); }
+    void add(const float* part, size_t stride, int nparts, size_t n, float* out, float alpha) {
+        if (!out || n == 0 || j.count == 4) return;
+        const int c = j.count++;
+        j.part[c] = part; j.stride[c] = stride; j.nparts[c] = nparts; j.n[c] = n; j.out[c] = out; j.alpha[c] = alpha;
+        j.first[c + 1] = j.first[c] + (unsigned)((n + RED_STRIP - 1) / RED_STRIP);
+    }
+    void launch(hipStream_t stream) {
+        if (j.count == 0) return;
+        hipLaunchKernelGGL(iefvad_reduce_parts_multi_kernel, dim3(j.first[j.count]), dim3(256), 0, stream, j);
+    }
+};
 
 // dW[n_out, 768] = alpha * dY^T X over the rows, split-K with fixed-order reduction; dW may be null (frozen parameter).
 // `dW2` (nullable) receives rows [n_split, n_out) as a tensor of its own (the stacked mu | logvar heads).
@@ -238,27 +253,16 @@ static int launch_dw(const float* dY, int ldy, int n_out, const float* X, float*
         else
             hipLaunchKernelGGL(iefvad_gemm_split_tn_kernel, dim3((unsigned)((n_out / 128) * g.tiles_n * slices)), dim3(256), TN_LDS_BYTES, stream, g);
         HIP_TRY(hipGetLastError());
-        if (dW) {
-            const size_t n = (size_t)(n_split > 0 ? n_split : n_out) * IEF_D;
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part, per, slices, n, dW, alpha);
-        }
-        if (dW2) {
-            const size_t n = (size_t)(n_out - n_split) * IEF_D;
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, part + (size_t)n_split * IEF_D,
-                               per, slices, n, dW2, alpha);
-        }
+        // one launch reduces the weight partials (both halves of a stacked product) and the bias partials that rode along
+        ReduceBatch rb;
+        rb.add(part, per, slices, (size_t)(n_split > 0 ? n_split : n_out) * IEF_D, dW, alpha);
+        if (dW2) rb.add(part + (size_t)n_split * IEF_D, per, slices, (size_t)(n_out - n_split) * IEF_D, dW2, alpha);
         if (with_db) {
-            if (db) {
-                const size_t n = n_split > 0 ? n_split : n_out;
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart, (size_t)n_out, slices, n, db, alpha);
-            }
-            if (db2) {
-                const size_t n = n_out - n_split;
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3((unsigned)((n + RED_STRIP - 1) / RED_STRIP)), dim3(256), 0, stream, cpart + n_split, (size_t)n_out, slices,
-                                   n, db2, alpha);
-            }
+            rb.add(cpart, (size_t)n_out, slices, (size_t)(n_split > 0 ? n_split : n_out), db, alpha);
+            if (db2) rb.add(cpart + n_split, (size_t)n_out, slices, (size_t)(n_out - n_split), db2, alpha);
             *db_done = true;
         }
+        rb.launch(stream);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -554,11 +558,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         sa.dlogit = dout->logits; sa.dfused = dout->fused; sa.z = ws + t.z[K]; sa.w = h->cls_w; sa.g = g;
         sa.part_w = rpart; sa.part_b = rpart + (size_t)nblk * IEF_D; sa.rows = rows;
         hipLaunchKernelGGL(iefvad_scorer_bwd_kernel, dim3(nblk), dim3(256), 0, stream, sa);
-        if (dw->cls_w)
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dw->cls_w, 1.f);
-        if (dw->cls_b)
-            hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(1), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)1, nblk, (size_t)1,
-                               dw->cls_b, 1.f);
+        ReduceBatch rb;
+        rb.add(rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dw->cls_w, 1.f);
+        rb.add(rpart + (size_t)nblk * IEF_D, (size_t)1, nblk, (size_t)1, dw->cls_b, 1.f);
+        rb.launch(stream);
         HIP_TRY(hipGetLastError());
     }
     // refinement steps, last to first (imf_vad.py:146-149): z_{k+1} = z_k - lambda (W2 relu(W1 z_k + b1) + b2); g = d z_{k+1}
@@ -604,11 +607,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             LnBwdArgs la;
             la.x = x; la.dy = gx; la.g = gamma; la.dx = gx; la.part_g = rpart; la.part_b = rpart + (size_t)nblk * IEF_D; la.rows = rows; la.eps = 1e-5f;
             hipLaunchKernelGGL(iefvad_layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, stream, la);
-            if (dgamma)
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dgamma, 1.f);
-            if (dbeta)
-                hipLaunchKernelGGL(iefvad_reduce_parts_kernel, dim3(IEF_D / RED_STRIP), dim3(256), 0, stream, rpart + (size_t)nblk * IEF_D, (size_t)IEF_D, nblk,
-                                   (size_t)IEF_D, dbeta, 1.f);
+            ReduceBatch rb;
+            rb.add(rpart, (size_t)IEF_D, nblk, (size_t)IEF_D, dgamma, 1.f);
+            rb.add(rpart + (size_t)nblk * IEF_D, (size_t)IEF_D, nblk, (size_t)IEF_D, dbeta, 1.f);
+            rb.launch(stream);
             HIP_TRY(hipGetLastError());
             return 0;
         };

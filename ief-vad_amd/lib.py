@@ -23,7 +23,7 @@ COMPUTE_CODES = {"f32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x6": COMPUTE_BF1
 
 # every symbol include/iefvad.h declares
 SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_workspace_bytes",
-           "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_last_error",
+           "iefvad_forward", "iefvad_forward_timed", "iefvad_gemm_bias", "iefvad_split_bf16x3", "iefvad_split_bf16x3_many", "iefvad_last_error",
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
@@ -200,6 +200,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_gemm_bias.restype = C.c_int
     lib.iefvad_split_bf16x3.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.iefvad_split_bf16x3.restype = C.c_int
+    lib.iefvad_split_bf16x3_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.iefvad_split_bf16x3_many.restype = C.c_int
     lib.iefvad_comm_unique_id.argtypes = [C.c_void_p]
     lib.iefvad_comm_unique_id.restype = C.c_int
     lib.iefvad_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]

@@ -442,6 +442,14 @@ int iefvad_gemm_bias(const void* A, const void* W, const float* bias, float* C,
  * for finite x.  What iefvad_set_weights applies to every projection matrix in IEFVAD_COMPUTE_BF16X6. */
 int iefvad_split_bf16x3(const float* src, void* planes, size_t n, void* stream);
 
+/* The same for `count` matrices in ONE launch per 32 of them -- what iefvad_set_weights and the training backward use (a training
+ * step re-splits every projection matrix and its transpose: 90 small launches before).  src / planes / n / rows are HOST arrays of
+ * device pointers and sizes.  rows[i] == 0: planes[i] receives the split of src[i] as above (n[i] % 4 == 0).  rows[i] == R > 0:
+ * src[i] is a row-major [R, n[i] / R] matrix and planes[i] receives the split of its TRANSPOSE [n[i] / R, R] (R % 64 == 0,
+ * (n[i] / R) % 32 == 0) -- the operand of dX = dY W as an NT product.  Bit for bit the planes of iefvad_split_bf16x3. */
+int iefvad_split_bf16x3_many(const float* const* src, void* const* planes, const size_t* n, const int32_t* rows, int32_t count,
+                             void* stream);
+
 /* ---- multi-GPU score gather ------------------------------------------------------------------
  * The reference has no collective at all (/root/reference/main.py:7 imports torch.distributed and never uses it);
  * what it fixes is the ORDER of the score vector: per-video scores are concatenated in test-list order and the

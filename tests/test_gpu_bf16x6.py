@@ -57,6 +57,35 @@ def test_three_term_split_is_exact():
     assert (np.abs(p[2][nz]) <= np.abs(x[nz]).astype(np.float64) * 2.0 ** -16).all()
 
 
+def test_many_matrix_split_and_transposed_split_equal_the_single_split():
+    """iefvad_split_bf16x3_many (one launch for every projection matrix of a model and, with rows > 0, for their transposes -- what
+    iefvad_set_weights and the training backward call): bit for bit the planes iefvad_split_bf16x3 gives for the matrix, respectively
+    for its torch transpose; 34 entries = two launches."""
+    lib = iefvad_amd.lib.load_library()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(2304, 768), (768, 768), (1536, 768)] * 5 + [(768, 768)] * 2
+    mats = [torch.randn(r, c, device="cuda", generator=gen) * float(np.exp(i - 8)) for i, (r, c) in enumerate(shapes)]
+    srcs, dsts, ns, rows, want = [], [], [], [], []
+    for i, m in enumerate(mats):
+        for transposed in (False, True):
+            out = torch.empty(3, m.numel(), dtype=torch.bfloat16, device="cuda")
+            ref = torch.empty_like(out)
+            base = m.t().contiguous() if transposed else m
+            assert lib.iefvad_split_bf16x3(base.data_ptr(), ref.data_ptr(), m.numel(), _stream()) == 0, iefvad_amd.lib.last_error()
+            srcs.append(m.data_ptr()); dsts.append(out.data_ptr()); ns.append(m.numel()); rows.append(m.shape[0] if transposed else 0)
+            want.append((ref, out))
+    cnt = len(srcs)
+    a_src = (C.c_void_p * cnt)(*srcs); a_dst = (C.c_void_p * cnt)(*dsts)
+    a_n = (C.c_size_t * cnt)(*ns); a_rows = (C.c_int32 * cnt)(*rows)
+    assert lib.iefvad_split_bf16x3_many(a_src, a_dst, a_n, a_rows, cnt, _stream()) == 0, iefvad_amd.lib.last_error()
+    torch.cuda.synchronize()
+    for j, (ref, out) in enumerate(want):
+        assert torch.equal(ref.view(torch.int16), out.view(torch.int16)), (j, rows[j])
+    a_rows[1] = 100      # not a multiple of 64
+    assert lib.iefvad_split_bf16x3_many(a_src, a_dst, a_n, a_rows, cnt, _stream()) != 0
+    assert "transposed split" in iefvad_amd.lib.last_error()
+
+
 def test_split_gemm_is_at_least_as_accurate_as_fp32_mfma():
     """C = A W^T + b: error of the split kernel vs an fp64 product <= error of the fp32 MFMA kernel (x 1.25 slack) on
     the three projection shapes, with asymmetric operands (a transposed accumulator map would show)."""

@@ -225,6 +225,56 @@ def test_fused_train_attention_equals_the_three_launch_path(mode, monkeypatch):
         assert float((o0["image_mu"].detach() - o1["image_mu"]).abs().mean()) > 1e-4
 
 
+@pytest.mark.parametrize("mode", ["library_generator", "injected_mask"])
+def test_train_forward_keeps_probabilities_and_mask_in_one_tensor(mode):
+    """bf16x6 train forward (csrc/attention_split.h TRAIN): ONE [B, 8, 256, 256] fp32 tensor per modality and layer carries
+    P = softmax(q k^T) in its magnitudes and the dropout mask in its sign bits (set = dropped).  Read straight out of the training
+    buffer (image modality, layer 0: behind x_0..x_L, q|k|v, the attention output and the pre-LayerNorm sum = (L + 6) U floats):
+    |stored| against the softmax of the stored q | k in fp64, the sign bits against the injected mask / the counter-based generator of
+    csrc/common.h re-derived here, the stored attention output against dropout(P) v.  (The first build passed an element of a register
+    vector to __builtin_bit_cast and hipcc read element 0 for all sixteen: 18 % sign bits and |P| off by 2e-3 -- this test is that
+    probe.)  /root/reference/model/imf_vad.py:70 (nn.MultiheadAttention(dropout=0.1) under train())."""
+    B, L, p = 3, 2, 0.1
+    img, ev, labels, lengths = batch(52, B)
+    model, _ = make_model(41, L, 2, "StudentT", 8, "bf16x6", p)
+    model.dropout_seed = 4321
+    mask = None
+    if mode == "injected_mask":
+        mask = torch.from_numpy(synth.make_dropout_mask(7, L, B, p)).cuda()
+        model.dropout_mask = mask
+    model.train()
+    out = model(img, ev, None, None, lengths)
+    ws = out["logits"].grad_fn.ws.view(torch.float32)
+    U, PU = B * 256 * 768, B * 8 * 256 * 256
+    qkv = ws[(L + 1) * U:(L + 4) * U].view(B, 256, 3, 8, 96)
+    att = ws[(L + 4) * U:(L + 5) * U].view(B, 256, 8, 96)
+    P = ws[(L + 6) * U:(L + 6) * U + PU].view(B, 8, 256, 256)
+    neg = P.view(torch.int32) < 0
+    q, k, v = (qkv[:, :, j].permute(0, 2, 1, 3).double() for j in range(3))      # q is stored pre-scaled by 1 / sqrt(96)
+    want = torch.softmax(q @ k.transpose(-1, -2), -1)
+    assert float((P.abs().double() - want).abs().max()) <= 1e-6
+    if mask is not None:
+        dropped = mask[0, 0] == 0
+    else:
+        M32 = 0xFFFFFFFF
+
+        def fmix32(x):
+            x = x & M32
+            x = x ^ (x >> 16); x = (x * 0x85EBCA6B) & M32
+            x = x ^ (x >> 13); x = (x * 0xC2B2AE35) & M32
+            return x ^ (x >> 16)
+        seed = (4321 * 0x100000001B3 + 1 * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF      # train.h: modality 0, layer 0
+        idx = torch.arange(PU, dtype=torch.int64, device="cuda")
+        a = fmix32((idx & M32) ^ (seed & M32))
+        bits = fmix32((a + (seed >> 32) + (idx >> 32) * 0x9E3779B1) & M32) >> 8
+        dropped = (bits < int(p * 16777216.0)).view(B, 8, 256, 256)
+    assert torch.equal(neg, dropped)
+    assert 0.08 < float(neg.float().mean()) < 0.12
+    Pd = torch.where(neg, torch.zeros_like(P), P * np.float32(1.0 / (1.0 - p))).double()
+    assert float((att.double() - (Pd @ v).permute(0, 2, 1, 3)).abs().max()) <= 2e-6
+    # ... and the backward reads the same tensor: gradients at the fp32 gates are covered by the fused-vs-three-launch test above
+
+
 def test_train_forward_without_dropout_equals_the_eval_forward():
     """p = 0: train() changes nothing in the reference's forward; here the train path computes attention on other kernels (scores
     and probabilities materialised) -- fp32 gates against the eval path, all eight outputs."""
