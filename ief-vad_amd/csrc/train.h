@@ -306,7 +306,14 @@ static int launch_db(const float* Y, int ld, int ncols, float* db, float* db2, i
 
 // What a train-mode forward leaves on the handle for its backward: which buffer it filled, at which batch size, and whether the
 // dropped copy of the probabilities exists.  A handful of forwards may be outstanding (one record per training buffer).
-struct TrainRecord { const void* ws; int B; bool drop[2][IEFVAD_MAX_LAYERS]; float drop_p[2][IEFVAD_MAX_LAYERS]; bool fused; unsigned long long stamp; };
+// Five saved tensors are also outputs (mu and logvar of both modalities, the refined state z_K = `fused`) and two are the inputs: where
+// the caller hands over fp32 buffers of its own, the forward writes / reads THOSE and the backward reads them again (x0, mu, lv, zK
+// below) -- seven device-to-device copies of [rows, 768] per step less (0.33 ms of a 26 ms step).  The caller keeps them untouched
+// until the backward has run (include/iefvad.h).
+struct TrainRecord {
+    const void* ws; int B; bool drop[2][IEFVAD_MAX_LAYERS]; float drop_p[2][IEFVAD_MAX_LAYERS]; bool fused; unsigned long long stamp;
+    const float* x0[2]; float* mu[2]; float* lv[2]; float* zK;
+};
 struct TrainState { TrainRecord rec[8]; unsigned long long clock = 0; };
 
 static void release_train(iefvad_handle* h) {
@@ -338,6 +345,8 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
     if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
         return fail("iefvad_train_forward: unknown in_dtype %d", in_dtype);
     if (((uintptr_t)img | (uintptr_t)ev) & 15) return fail("iefvad_train_forward: buffers must be 16-byte aligned");
+    if (((uintptr_t)out->fused | (uintptr_t)out->image_mu | (uintptr_t)out->event_mu | (uintptr_t)out->image_logvar | (uintptr_t)out->event_logvar) & 15)
+        return fail("iefvad_train_forward: output buffers must be 16-byte aligned");
     const iefvad_config& c = h->cfg;
     const int L = c.num_layers, K = c.num_steps;
     for (int m = 0; m < 2; ++m)
@@ -354,6 +363,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         if (!h->train) return fail("iefvad_train_forward: out of host memory");
         memset(h->train->rec, 0, sizeof(h->train->rec));
     }
+    TrainRecord* rec = nullptr;
     {   // the record of this forward replaces the one of the same buffer, else the oldest
         TrainState& ts = *h->train;
         int slot = 0;
@@ -362,7 +372,16 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             if (ts.rec[i].stamp < ts.rec[slot].stamp) slot = i;
         }
         TrainRecord& r = ts.rec[slot];
+        rec = &r;
         r.ws = train_ws; r.B = B; r.fused = fused; r.stamp = ++ts.clock;
+        const bool f32in = in_dtype == IEFVAD_IN_F32;
+        r.x0[0] = f32in ? (const float*)img : ws + t.x[0][0];
+        r.x0[1] = f32in ? (const float*)ev : ws + t.x[1][0];
+        r.mu[0] = out->image_mu ? out->image_mu : ws + t.mu[0];
+        r.mu[1] = out->event_mu ? out->event_mu : ws + t.mu[1];
+        r.lv[0] = out->image_logvar ? out->image_logvar : ws + t.lv[0];
+        r.lv[1] = out->event_logvar ? out->event_logvar : ws + t.lv[1];
+        r.zK = out->fused ? out->fused : ws + t.z[K];
         for (int m = 0; m < 2; ++m)
             for (int l = 0; l < IEFVAD_MAX_LAYERS; ++l) {
                 r.drop[m][l] = l < L && (opt->dropout_p[m][l] > 0.f || opt->keep_mask);
@@ -373,11 +392,10 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
     const float qscale = 1.0f / sqrtf((float)IEF_DH);
     const float factor = (c.noise_model == IEFVAD_NOISE_STUDENT_T) ? (c.nu + 1.0f) / c.nu : 1.0f;
 
-    // `.to(torch.float)` (imf_vad.py:41-42) into the saved layer-0 inputs
-    if (in_dtype == IEFVAD_IN_F32) {
-        HIP_TRY(hipMemcpyAsync(ws + t.x[0][0], img, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(ws + t.x[1][0], ev, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    } else {
+    // `.to(torch.float)` (imf_vad.py:41-42) into the saved layer-0 inputs; fp32 inputs are read where they are
+    auto xin = [&](int m, int l) -> const float* { return l == 0 ? rec->x0[m] : ws + t.x[m][l]; };
+    auto zst = [&](int k) -> float* { return k == K ? rec->zK : ws + t.z[k]; };
+    if (in_dtype != IEFVAD_IN_F32) {
         const int rc = (in_dtype == IEFVAD_IN_F16)
                            ? launch_cast<__half>(img, ev, ws + t.x[0][0], ws + t.x[1][0], nullptr, nullptr, t.U, 2, stream)
                            : launch_cast<__hip_bfloat16>(img, ev, ws + t.x[0][0], ws + t.x[1][0], nullptr, nullptr, t.U, 2, stream);
@@ -390,7 +408,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         p.N = 3 * IEF_D; p.ldc = 3 * IEF_D; p.epi = EPI_QKV; p.qcols = IEF_D; p.nz = 2;
         p.alpha = qscale;                               // q * 1/sqrt(dh) before the bmm, as F.multi_head_attention_forward does
         for (int m = 0; m < 2; ++m) {
-            p.A32[m] = ws + t.x[m][l]; p.W32[m] = h->in_w[m][l]; p.Ws[m] = h->in_ws[m][l]; p.bias[m] = h->in_b[m][l];
+            p.A32[m] = xin(m, l); p.W32[m] = h->in_w[m][l]; p.Ws[m] = h->in_ws[m][l]; p.bias[m] = h->in_b[m][l];
             p.C[m] = ws + t.qkv[m][l];
         }
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_QKV)) return rc;
@@ -455,7 +473,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RESID; p.nz = 2;
         for (int m = 0; m < 2; ++m) {
             p.A32[m] = ws + t.att[m][l]; p.W32[m] = h->out_w[m][l]; p.Ws[m] = h->out_ws[m][l]; p.bias[m] = h->out_b[m][l];
-            p.C[m] = ws + t.s[m][l]; p.R[m] = ws + t.x[m][l];
+            p.C[m] = ws + t.s[m][l]; p.R[m] = xin(m, l);
         }
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_OUT)) return rc;
 
@@ -484,15 +502,15 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         p.N = 2 * IEF_D; p.ldc = IEF_D; p.epi = EPI_HEADS; p.nz = 2;
         for (int m = 0; m < 2; ++m) {
             p.A32[m] = ws + t.E[m]; p.W32[m] = h->head_w[m]; p.Ws[m] = h->head_ws[m]; p.bias[m] = h->head_b[m];
-            p.C[m] = ws + t.mu[m]; p.C2[m] = ws + t.lv[m];
+            p.C[m] = rec->mu[m]; p.C2[m] = rec->lv[m];
         }
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_HEAD)) return rc;
     }
     {
         FusionArgs fa;
         memset(&fa, 0, sizeof(fa));
-        fa.mu_i = ws + t.mu[0]; fa.lv_i = ws + t.lv[0]; fa.mu_e = ws + t.mu[1]; fa.lv_e = ws + t.lv[1];
-        fa.n_i = out->w_i; fa.n_e = out->w_e; fa.z = ws + t.z[0];
+        fa.mu_i = rec->mu[0]; fa.lv_i = rec->lv[0]; fa.mu_e = rec->mu[1]; fa.lv_e = rec->lv[1];
+        fa.n_i = out->w_i; fa.n_e = out->w_e; fa.z = zst(0);
         fa.n_i_mean = out->w_i_mean; fa.n_e_mean = out->w_e_mean;
         fa.nrows = rows; fa.factor = factor; fa.eps = c.epsilon;
         hipLaunchKernelGGL(iefvad_fusion_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, fa);
@@ -502,23 +520,19 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
         Proj p;
         memset(&p, 0, sizeof(p));
         p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_BIAS_RELU; p.nz = 1;
-        p.A32[0] = ws + t.z[k]; p.W32[0] = h->ref_w1[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k]; p.C[0] = ws + t.hid[k];
+        p.A32[0] = zst(k); p.W32[0] = h->ref_w1[k]; p.Ws[0] = h->ref_w1s[k]; p.bias[0] = h->ref_b1[k]; p.C[0] = ws + t.hid[k];
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
         memset(&p, 0, sizeof(p));
         p.N = IEF_D; p.ldc = IEF_D; p.epi = EPI_REFINE; p.alpha = c.lambda_ref; p.nz = 1;
         p.A32[0] = ws + t.hid[k]; p.W32[0] = h->ref_w2[k]; p.Ws[0] = h->ref_w2s[k]; p.bias[0] = h->ref_b2[k];
-        p.C[0] = ws + t.z[k + 1]; p.R[0] = ws + t.z[k];
+        p.C[0] = zst(k + 1); p.R[0] = zst(k);
         if (int rc = launch_proj(p, c.compute, splitmb, rows, stream, tm, ST_REFINE)) return rc;
     }
     float* logits = out->logits ? out->logits : ws + t.logits;
-    hipLaunchKernelGGL(iefvad_scorer_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, ws + t.z[K], h->cls_w, h->cls_b,
+    hipLaunchKernelGGL(iefvad_scorer_kernel, dim3((rows + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, stream, rec->zK, h->cls_w, h->cls_b,
                        logits, rows);
     HIP_TRY(hipGetLastError());
-    // the caller's copies of the dict entries (imf_vad.py:152-161)
-    const struct { float* dst; size_t src; } cp[5] = {{out->fused, t.z[K]}, {out->image_mu, t.mu[0]}, {out->event_mu, t.mu[1]},
-                                                       {out->image_logvar, t.lv[0]}, {out->event_logvar, t.lv[1]}};
-    for (const auto& e : cp)
-        if (e.dst) HIP_TRY(hipMemcpyAsync(e.dst, ws + e.src, t.U * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // (the dict entries of imf_vad.py:152-161 that are also saved tensors were written in place: TrainRecord)
     return 0;
 }
 
@@ -555,7 +569,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
     // classifier (imf_vad.py:150)
     {
         ScorerBwdArgs sa;
-        sa.dlogit = dout->logits; sa.dfused = dout->fused; sa.z = ws + t.z[K]; sa.w = h->cls_w; sa.g = g;
+        sa.dlogit = dout->logits; sa.dfused = dout->fused; sa.z = rec->zK; sa.w = h->cls_w; sa.g = g;
         sa.part_w = rpart; sa.part_b = rpart + (size_t)nblk * IEF_D; sa.rows = rows;
         hipLaunchKernelGGL(iefvad_scorer_bwd_kernel, dim3(nblk), dim3(256), 0, stream, sa);
         ReduceBatch rb;
@@ -574,7 +588,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         // d a = (-lambda g W2) gated by h > 0  (ReLU backward on the saved activation)
         if (int rc = launch_dx(h, tp ? h->ref_w2st[k] : nullptr, g, IEF_D, h->ref_w2[k], IEF_D, IEF_D, da, nullptr, ws + t.hid[k], nl, rows, stream)) return rc;
         { bool db_done = false;
-            if (int rc = launch_dw(da, IEF_D, IEF_D, ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->ref_b1[k], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (int rc = launch_dw(da, IEF_D, IEF_D, k == K ? rec->zK : ws + t.z[k], dw->ref_w1[k], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->ref_b1[k], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
             if (!db_done)
                 if (int rc = launch_db(da, IEF_D, IEF_D, dw->ref_b1[k], nullptr, 0, 1.f, rows, cpart, stream)) return rc; }
         // d z_k = g + d a W1   (in place: every element of g is read by the thread that overwrites it)
@@ -584,7 +598,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
     {
         FusionBwdArgs fa;
         memset(&fa, 0, sizeof(fa));
-        fa.mu_i = ws + t.mu[0]; fa.lv_i = ws + t.lv[0]; fa.mu_e = ws + t.mu[1]; fa.lv_e = ws + t.lv[1];
+        fa.mu_i = rec->mu[0]; fa.lv_i = rec->lv[0]; fa.mu_e = rec->mu[1]; fa.lv_e = rec->lv[1];
         fa.gz = g;
         fa.d_mu_i = dout->image_mu; fa.d_lv_i = dout->image_logvar; fa.d_mu_e = dout->event_mu; fa.d_lv_e = dout->event_logvar;
         fa.d_n_i = dout->w_i; fa.d_n_e = dout->w_e;
@@ -689,7 +703,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             if (int rc = launch_bgemm(a, false, false, B * IEF_H, stream)) return rc;
             // in_proj (packed q | k | v, imf_vad.py:69-72)
             { bool db_done = false;
-            if (int rc = launch_dw(dqkv, 3 * IEF_D, 3 * IEF_D, ws + t.x[m][l], dw->in_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->in_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
+            if (int rc = launch_dw(dqkv, 3 * IEF_D, 3 * IEF_D, l == 0 ? rec->x0[m] : ws + t.x[m][l], dw->in_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->in_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
             if (!db_done)
                 if (int rc = launch_db(dqkv, 3 * IEF_D, 3 * IEF_D, dw->in_proj_b[m][l], nullptr, 0, 1.f, rows, cpart, stream)) return rc; }
             // d x_l = d s_l (residual) + d qkv W_in; the input features need no gradient

@@ -157,7 +157,11 @@ class _TrainForward(torch.autograd.Function):
         ctx.model, ctx.ws, ctx.B, ctx.mask = model, ws, B, mask
         ctx.params = params
         ctx.set_materialize_grads(False)     # backward takes None as "no gradient": no zero-filled [B,T,768] tensors for unused outputs
-        return tuple(res[k] for k in OUTPUT_KEYS)
+        outs = tuple(res[k] for k in OUTPUT_KEYS)
+        # the library wrote five of the outputs in place and reads them, and fp32 inputs, again in the backward (include/iefvad.h):
+        # saved here so that they stay alive and an in-place edit between the two passes raises as it would in the reference
+        ctx.save_for_backward(img, ev, *(res[k] for k in ("fused", "image_mu", "event_mu", "image_logvar", "event_logvar")))
+        return outs
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -165,6 +169,7 @@ class _TrainForward(torch.autograd.Function):
         model, ws = ctx.model, ctx.ws
         if ws is None:
             raise RuntimeError("iefvad_amd.MMFMIL: backward through the same forward twice (the activations were released)")
+        _ = ctx.saved_tensors               # version check of the tensors the library reads again
         device = ws.device
         keep = []
         dout = _lib.OutputGrads()

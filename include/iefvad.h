@@ -245,7 +245,10 @@ int iefvad_loss_backward(const float* logits, const float* image_mu, const float
  * iefvad_train_forward computes the eight outputs like iefvad_forward and keeps what the backward needs in `train_ws`
  * (iefvad_train_workspace_bytes; 256-byte aligned; owned by the caller, who keeps it untouched until the matching
  * iefvad_train_backward has run on the same stream).  compute must be IEFVAD_COMPUTE_F32 or IEFVAD_COMPUTE_BF16X6 (fp32-accurate);
- * the whole batch runs as one pass (B <= 4096).  ONE backward per forward: the backward's scratch tensors overwrite saved states
+ * the whole batch runs as one pass (B <= 4096).  Five of the outputs are also saved tensors (fused, image_mu, event_mu, image_logvar,
+ * event_logvar) and fp32 inputs are saved as they are: the forward writes / reads the caller's buffers in place and the backward
+ * READS THEM AGAIN, so `img`, `ev` (in_dtype f32) and those five output buffers stay untouched until iefvad_train_backward has run
+ * (a null output pointer keeps that tensor in train_ws).  ONE backward per forward: the backward's scratch tensors overwrite saved states
  * it has already differentiated, so a second iefvad_train_backward on the same buffer fails ("no iefvad_train_forward ...") until a
  * new forward has filled it.
  *   dropout_p[m][l]  the probability nn.MultiheadAttention m / layer l drops an attention weight with (0 = none); kept weights
