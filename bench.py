@@ -490,10 +490,11 @@ def train_step_one(dev, a, compute, chunks=128, steps=4):
            "mfma_pipe_util": flops / dt / 1e12 * (PRODUCTS_PER_MAC[compute]) / peak,
            "peak_note": ("whole-step algorithmic FLOPs (3 x the forward's) over wall time against the dense bf16 MFMA peak; mfma_pipe_util counts the six "
                          "executed bf16 products per multiply-add of the projection products (of the attention products, S, Pd v, d Pd and d q run on "
-                         "the same split arithmetic inside two fused launches per layer, d v and d k on the fp32 MFMA instruction, and the row "
+                         "the same split arithmetic inside two fused launches per layer with P and its dropout mask as ONE stored tensor, d v and d k on the fp32 MFMA instruction, and the row "
                          "kernels on none, so this is an upper bound on the pipe's real occupancy)") if split else
                         "whole-step algorithmic FLOPs over wall time against the fp32 MFMA peak: every product on v_mfma_f32_32x32x2_f32",
-           "loss_total": float(terms["total"])}
+           "loss_total": float(terms["total"]),
+           "activation_buffer_gib": iefvad_amd.lib.load_library().iefvad_train_workspace_bytes(model._handle, chunks) / 2**30}
     return out
 
 

@@ -334,6 +334,45 @@ static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t
     return 0;
 }
 
+// ---- the trainers' NaN rule on the device ----------------------------------------------------------------------------------------------
+// /root/reference/train/ucf_train.py:50-53 (xd_train.py:40-43): `if torch.isnan(x).any(): x = torch.nan_to_num(x, nan=0.0)` per input
+// tensor -- in torch an isnan pass that writes a bool tensor, a reduction, a HOST read of the flag (the step's launches cannot run
+// ahead of the device) and, when it fires, a rewriting pass.  Here: one scan of both tensors (a flag word each, set by any thread
+// that sees a NaN) and a repair launch whose workgroups return at once when their tensor's flag is clear; nothing comes back to the
+// host.  The repair is torch.nan_to_num(x, nan=0.0) element for element (NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX), IN PLACE.
+__global__ __launch_bounds__(256) void iefvad_nan_scan_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n4, unsigned* flags) {
+    const float* x = blockIdx.y ? b : a;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        bad |= (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1u;      // every writer writes the same value
+}
+__global__ __launch_bounds__(256) void iefvad_nan_fix_kernel(float* a, float* b, size_t n4, const unsigned* flags) {
+    if (!flags[blockIdx.y]) return;
+    float* x = blockIdx.y ? b : a;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = ((f32x4*)x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = v[e];
+            v[e] = f != f ? 0.f : f == __builtin_inff() ? 3.402823466e+38f : f == -__builtin_inff() ? -3.402823466e+38f : f;
+        }
+        ((f32x4*)x)[i] = v;
+    }
+}
+extern "C" int iefvad_nan_rule(float* a, float* b, size_t n, void* flags_ws, void* stream_) {
+    if (!a || !b || !flags_ws) return fail("iefvad_nan_rule: null argument");
+    if (n % 4 || (((uintptr_t)a | (uintptr_t)b) & 15) || ((uintptr_t)flags_ws & 7)) return fail("iefvad_nan_rule: n %% 4 == 0 and 16-byte aligned tensors, please");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipMemsetAsync(flags_ws, 0, 8, stream));
+    hipLaunchKernelGGL(iefvad_nan_scan_kernel, dim3(2048, 2), dim3(256), 0, stream, a, b, n / 4, (unsigned*)flags_ws);
+    hipLaunchKernelGGL(iefvad_nan_fix_kernel, dim3(2048, 2), dim3(256), 0, stream, a, b, n / 4, (const unsigned*)flags_ws);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- train-mode forward -------------------------------------------------------------------------------------------------------------
 extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const void* ev, int32_t in_dtype, int32_t B,
                                     const iefvad_train_options* opt, void* train_ws, size_t train_ws_bytes, const iefvad_outputs* out,

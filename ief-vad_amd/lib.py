@@ -27,7 +27,7 @@ SYMBOLS = ["iefvad_abi_version", "iefvad_create", "iefvad_set_weights", "iefvad_
            "iefvad_destroy", "iefvad_comm_unique_id", "iefvad_comm_create", "iefvad_comm_nranks", "iefvad_comm_destroy",
            "iefvad_gather_scores", "iefvad_gather_plan", "iefvad_rccl_version", "iefvad_forward_videos",
            "iefvad_videos_workspace_bytes", "iefvad_host_gather", "iefvad_loss_forward", "iefvad_loss_backward", "iefvad_adamw_step",
-           "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward",
+           "iefvad_loss_workspace_bytes", "iefvad_train_workspace_bytes", "iefvad_train_forward", "iefvad_train_backward", "iefvad_nan_rule",
            "iefvad_forward_videos_host", "iefvad_host_gather_bf16", "iefvad_auc_ap", "iefvad_auc_ap_workspace_bytes", "iefvad_forward_scaled", "iefvad_rowblock_unit",
            "iefvad_similarity_adj", "iefvad_similarity_adj_workspace_bytes", "iefvad_distance_adj", "iefvad_gcn_forward",
            "iefvad_gcn_workspace_bytes", "iefvad_gat_forward", "iefvad_gat_workspace_bytes", "iefvad_resblock_forward",
@@ -202,6 +202,8 @@ def load_library() -> C.CDLL:
     lib.iefvad_split_bf16x3.restype = C.c_int
     lib.iefvad_split_bf16x3_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.iefvad_split_bf16x3_many.restype = C.c_int
+    lib.iefvad_nan_rule.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.iefvad_nan_rule.restype = C.c_int
     lib.iefvad_comm_unique_id.argtypes = [C.c_void_p]
     lib.iefvad_comm_unique_id.restype = C.c_int
     lib.iefvad_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]

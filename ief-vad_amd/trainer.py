@@ -51,6 +51,30 @@ def _nan_rule(x: torch.Tensor) -> torch.Tensor:
     return torch.nan_to_num(x, nan=0.0) if bool(torch.isnan(x).any()) else x          # ucf_train.py:50-53
 
 
+_NAN_FLAGS = {}
+
+
+def _nan_rule_pair(img: torch.Tensor, ev: torch.Tensor):
+    """ucf_train.py:50-53 for both inputs of a step.  fp32 device tensors go through `iefvad_nan_rule`: one scan + one repair launch,
+    the flag never read by the host (torch's form costs an isnan pass, a reduction and a device-to-host wait per tensor and step);
+    a tensor that does hold a NaN is repaired IN PLACE (the loops hand over per-step temporaries).  Anything else: the torch form."""
+    ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 and t.data_ptr() % 16 == 0 for t in (img, ev))
+    if not ok or img.numel() != ev.numel() or img.device != ev.device:
+        return _nan_rule(img), _nan_rule(ev)
+    import ctypes as C
+    from . import lib as _lib
+    dev = img.device
+    flags = _NAN_FLAGS.get(dev)
+    if flags is None:
+        flags = _NAN_FLAGS[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load_library().iefvad_nan_rule(C.c_void_p(img.data_ptr()), C.c_void_p(ev.data_ptr()), img.numel(), C.c_void_p(flags.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("iefvad_nan_rule: " + _lib.last_error())
+    return img, ev
+
+
 def train_step(model, optimizer, img: torch.Tensor, ev: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor,
                noise_model: str = "StudentT", lambda_reg: float = 1.0, lambda_kl: float = 1.0, nan_to_num: bool = True,
                want_terms: bool = True) -> Optional[Dict[str, torch.Tensor]]:
@@ -59,7 +83,7 @@ def train_step(model, optimizer, img: torch.Tensor, ev: torch.Tensor, labels: to
     ucf_train.py:108-128 prints every `print_steps` samples)."""
     model.train()
     if nan_to_num:
-        img, ev = _nan_rule(img), _nan_rule(ev)
+        img, ev = _nan_rule_pair(img, ev)
     out = model(img, ev, None, None, lengths)
     nu = model.temporal.nu                                                             # ucf_train.py:94-95 reads it there
     total = losses.training_loss(out, labels, lengths, noise_model, nu, lambda_reg, lambda_kl)

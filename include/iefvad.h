@@ -299,6 +299,13 @@ int iefvad_train_forward(iefvad_handle* h, const void* img, const void* ev, int3
 int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws, size_t train_ws_bytes, const iefvad_output_grads* dout,
                           const iefvad_weight_grads* dw, void* stream);
 
+/* The trainers' input rule (/root/reference/train/ucf_train.py:50-53, xd_train.py:40-43: `if torch.isnan(x).any(): x =
+ * torch.nan_to_num(x, nan=0.0)`, per tensor) for the two fp32 input tensors of a step, without the host read of the flag: one scan,
+ * one repair launch that returns at once for a tensor without NaN; a tensor WITH a NaN is rewritten IN PLACE as torch.nan_to_num
+ * does (NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX).  a, b: device, n floats each (n % 4 == 0, 16-byte aligned); flags_ws: 8 device
+ * bytes (8-byte aligned) that hold the two flags afterwards (1 = that tensor had a NaN). */
+int iefvad_nan_rule(float* a, float* b, size_t n, void* flags_ws, void* stream);
+
 /* One torch.optim.AdamW step (as /root/reference/train/ucf_train.py:28 constructs it: betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01, amsgrad off) on one flat fp32 tensor, in place, in torch's operation order; `step` counts from 1.  The hyper-parameters
  * travel as doubles: torch forms 1 - lr wd, 1 - beta1, 1 - beta2, lr / (1 - beta1^t) and sqrt(1 - beta2^t) in Python floats

@@ -435,6 +435,31 @@ def test_adamw_is_a_torch_optimizer_scheduler_and_state_dict_interchange():
         losses.AdamW([torch.zeros(4)])
 
 
+def test_nan_rule_on_the_device_is_the_trainers_rule():
+    """/root/reference/train/ucf_train.py:50-53 per input tensor: `if torch.isnan(x).any(): x = torch.nan_to_num(x, nan=0.0)` --
+    a tensor WITH a NaN is rewritten as nan_to_num does (its infinities too), one without keeps every bit (its infinities too);
+    `iefvad_nan_rule` does it without the host reading the flag (trainer._nan_rule_pair), in place."""
+    from iefvad_amd import trainer
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randn(4, 256, 768, device="cuda", generator=gen)
+    ev = torch.randn(4, 256, 768, device="cuda", generator=gen)
+    img[1, 7, 5] = float("nan"); img[3, 255, 767] = float("nan"); img[0, 0, 0] = float("inf"); img[2, 9, 9] = float("-inf")
+    ev[2, 3, 4] = float("inf"); ev[0, 1, 2] = float("-inf")
+    want_img = torch.nan_to_num(img, nan=0.0)
+    want_ev = ev.clone()
+    a, b = trainer._nan_rule_pair(img, ev)
+    assert a.data_ptr() == img.data_ptr() and b.data_ptr() == ev.data_ptr()
+    assert torch.equal(a.view(torch.int32), want_img.view(torch.int32))
+    assert torch.equal(b.view(torch.int32), want_ev.view(torch.int32))
+    assert trainer._NAN_FLAGS[img.device].tolist() == [1, 0]
+    # the other way round, and the torch form for what the kernel does not take (fp16 rows)
+    a, b = trainer._nan_rule_pair(ev, want_img)
+    assert torch.equal(a.view(torch.int32), want_ev.view(torch.int32)) and trainer._NAN_FLAGS[img.device].tolist() == [0, 0]
+    h = torch.tensor([1.0, float("nan"), float("inf"), 2.0], device="cuda", dtype=torch.float16)
+    a, _ = trainer._nan_rule_pair(h, h.clone())
+    assert torch.equal(a, torch.nan_to_num(h, nan=0.0))
+
+
 def test_train_mode_error_paths():
     model, _ = make_model(37, 1, 0, "StudentT", 8, compute="bf16")
     model.train()
@@ -450,9 +475,24 @@ def test_train_mode_error_paths():
         model(x, x, None, None, None)
     model.dropout_mask = None
     out = model(x, x, None, None, None)
+    ws = out["logits"].grad_fn.ws                 # keep the training buffer past the node's own release
     out["logits"].sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="twice"):
         out["fused"].sum().backward()
+    # ... and the library itself: the backward's scratch overwrote saved states, so the forward's record is retired and a second
+    # iefvad_train_backward on the same buffer fails by name instead of differentiating garbage (include/iefvad.h)
+    import ctypes as C
+    from iefvad_amd import lib as L_
+    lib = L_.load_library()
+    dout, dw = L_.OutputGrads(), L_.WeightGrads()
+    rc = lib.iefvad_train_backward(model._handle, 1, C.c_void_p(ws.data_ptr()), ws.numel(), C.byref(dout), C.byref(dw),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and "no iefvad_train_forward" in L_.last_error()
+    # an in-place edit of an output the library reads again in the backward raises, as autograd does for the reference's modules
+    out = model(x, x, None, None, None)
+    out["image_mu"].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["logits"].sum().backward()
 
 
 def test_paired_training_loop_keeps_the_reference_bookkeeping(tmp_path, monkeypatch):
