@@ -10,7 +10,7 @@
 //                                  S = q k^T, dP = dA v^T   (both k-contiguous), A = P v, dQ = dS k, dK = dS^T q, dV = P^T dA
 //                                  (batched over (chunk, head) with two-level strides)
 //   iefvad_softmax_dropout_kernel  softmax over the 256 keys + attention dropout (imf_vad.py:70: nn.MultiheadAttention(dropout=0.1),
-//                                  active in train()); keeps P and the dropped / rescaled P_d
+//                                  active in train()); keeps P with the mask in its sign bits
 //   iefvad_softmax_bwd_kernel      dS = P_d .* dP_d - P * rowsum(P_d .* dP_d)
 //   iefvad_scorer_bwd_kernel       classifier (imf_vad.py:150):  dz = dlogit w_c (+ d fused), partial sums for dw_c, db_c
 //   iefvad_fusion_bwd_kernel       precision weights + fusion (imf_vad.py:130-144), literal expression graph
@@ -192,11 +192,12 @@ __global__ __launch_bounds__(256, 2) void iefvad_bgemm_f32_kernel(BgemmArgs a) {
 // (the counter-based mask generator `dropout_bits` lives in common.h: the fused train-mode attention kernel draws the same bits)
 
 // One wavefront per score row (256 keys, 4 per lane).  S holds q k^T / sqrt(96) (q is pre-scaled by the in_proj epilogue, as
-// F.multi_head_attention_forward scales q before the bmm).  P = softmax(S) is written over S; Pd = dropout(P) (kept entries
-// times 1 / (1 - p)) goes to its own buffer unless p == 0 and no mask is given (then Pd is P and `Pd` is null).
+// F.multi_head_attention_forward scales q before the bmm).  P = softmax(S) is written over S with the dropout mask in its SIGN bits
+// (set = dropped; common.h: one tensor carries P = |stored| and dropout(P) = sign ? 0 : stored / (1 - p), as the fused launches of
+// attention_split.h keep it): the products that read dropout(P) form it on the way (BgemmArgs.a_drop).
 struct SoftmaxDropArgs {
-    float* S;                    // [rows, 256] in: scores, out: P
-    float* Pd;                   // [rows, 256] nullable
+    float* S;                    // [rows, 256] in: scores, out: sign-carrying P
+    int drop;                    // dropout in force (p > 0 or an injected mask)
     const unsigned char* keep;   // [rows, 256] injected mask (1 = keep), nullable
     unsigned long long seed;     // RNG stream of this (layer, modality)
     float p;                     // dropout probability
@@ -215,36 +216,33 @@ __global__ __launch_bounds__(256) void iefvad_softmax_dropout_kernel(SoftmaxDrop
     s = wave_sum(s);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] / s;
-    *(f32x4*)sp = v;
-    if (a.Pd) {
-        const float scale = (float)(1.0 / (1.0 - (double)a.p));
+    if (a.drop) {
         const unsigned thr = (unsigned)((double)a.p * 16777216.0);
-        f32x4 d;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned long long idx = (unsigned long long)row * 256 + 4 * lane + e;
             const bool k = a.keep ? a.keep[idx] != 0 : dropout_bits(a.seed, idx) >= thr;
-            d[e] = k ? v[e] * scale : 0.f;
+            v[e] = with_sign_bit(v[e], k ? 0u : 0x80000000u);
         }
-        *(f32x4*)(a.Pd + row * 256 + 4 * lane) = d;
     }
+    *(f32x4*)sp = v;
 }
 
 // dS = P .* (dP - D), with dP = dPd .* keep / (1 - p) and D = rowsum(P .* dP): since P .* keep / (1 - p) = Pd,
-// dS = Pd .* dPd - P * rowsum(Pd .* dPd).  In place over dPd.
-__global__ __launch_bounds__(256) void iefvad_softmax_bwd_kernel(const float* P, const float* Pd, float* dPd, long long rows) {
+// dS = Pd .* dPd - P * rowsum(Pd .* dPd).  In place over dPd.  `Ps`: the sign-carrying P, `scale` = 1 / (1 - p) as the forward rounded it.
+__global__ __launch_bounds__(256) void iefvad_softmax_bwd_kernel(const float* Ps, float scale, float* dPd, long long rows) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const size_t o = (size_t)row * 256 + 4 * lane;
-    const f32x4 p = *(const f32x4*)(P + o), pd = *(const f32x4*)(Pd + o);
+    const f32x4 ps = *(const f32x4*)(Ps + o);
     f32x4 g = *(const f32x4*)(dPd + o);
     float d = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g[e] = pd[e] * g[e]; d += g[e]; }
+    for (int e = 0; e < 4; ++e) { g[e] = dropped_from_signed(ps[e], scale) * g[e]; d += g[e]; }
     d = wave_sum(d);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = g[e] - p[e] * d;
+    for (int e = 0; e < 4; ++e) g[e] = g[e] - __builtin_fabsf(ps[e]) * d;
     *(f32x4*)(dPd + o) = g;
 }
 

@@ -6,8 +6,8 @@
 //   iefvad_train_forward   the forward of imf_vad.py:109-161 in train mode (attention dropout, imf_vad.py:70) that KEEPS what the
 //                          backward needs, in a caller-owned buffer:
 //                            per modality and layer: the layer input x_l, q | k | v (q pre-scaled by 1 / sqrt(96)), the attention
-//                            probabilities P (bf16x6: ONE tensor, the dropout mask in its sign bits -- attention_split.h; f32:
-//                            P and its dropped copy), the attention output, the pre-LayerNorm sum;
+//                            probabilities P (ONE tensor, the dropout mask in its sign bits -- attention_split.h, backward.h),
+//                            the attention output, the pre-LayerNorm sum;
 //                            the last LayerNorm output, the whitened rows, mu and logvar of both modalities;
 //                            the refinement states z_0 .. z_K and hidden activations h_0 .. h_{K-1}
 //   iefvad_train_backward  the gradients of every parameter, given the gradients of the eight outputs
@@ -21,7 +21,7 @@ struct TrainLayout {
     size_t U;                       // one [rows, 768] tensor
     size_t PU;                      // one [B, 8, 256, 256] tensor
     size_t x[2][IEFVAD_MAX_LAYERS + 1], qkv[2][IEFVAD_MAX_LAYERS], att[2][IEFVAD_MAX_LAYERS], s[2][IEFVAD_MAX_LAYERS];
-    size_t P[2][IEFVAD_MAX_LAYERS], Pd[2][IEFVAD_MAX_LAYERS];
+    size_t P[2][IEFVAD_MAX_LAYERS];
     size_t E[2], mu[2], lv[2];
     size_t z[IEFVAD_MAX_STEPS + 1], hid[IEFVAD_MAX_STEPS];
     size_t logits;
@@ -41,15 +41,15 @@ static int splitk_splits(int rows, int n_out) {
     return s;
 }
 
-// The fused train-mode attention launches (bf16x6; attention_split.h TRAIN / BWD) keep P and dropout(P) as ONE sign-carrying tensor;
-// the three-launch path (f32 arithmetic, or IEFVAD_TRAIN_ATTN=unfused for the A/B test) keeps two.  The switch is read when a buffer
-// is sized and when a forward starts; the backward follows its forward's record.
+// Train-mode attention runs as two fused launches per layer in bf16x6 (attention_split.h TRAIN / BWD) and as the three-launch path in
+// the f32 arithmetic (or with IEFVAD_TRAIN_ATTN=unfused, the A/B test's switch, read when a forward starts; the backward follows its
+// forward's record).  Both keep P and dropout(P) as ONE sign-carrying tensor: the layout is the same.
 static bool train_attn_fused(const iefvad_handle* h) {
     const char* v = getenv("IEFVAD_TRAIN_ATTN");
     return h->cfg.compute == IEFVAD_COMPUTE_BF16X6 && !(v && v[0] == 'u');
 }
 
-static TrainLayout train_layout(int L, int K, int B, bool signed_p) {
+static TrainLayout train_layout(int L, int K, int B) {
     TrainLayout t;
     memset(&t, 0, sizeof(t));
     const size_t rows = (size_t)B * IEF_T;
@@ -64,7 +64,6 @@ static TrainLayout train_layout(int L, int K, int B, bool signed_p) {
             t.att[m][l] = take(t.U);
             t.s[m][l] = take(t.U);
             t.P[m][l] = take(t.PU);
-            t.Pd[m][l] = signed_p ? t.P[m][l] : take(t.PU);
         }
         t.E[m] = take(t.U);
         t.mu[m] = take(t.U);
@@ -112,7 +111,7 @@ static TrainLayout train_layout(int L, int K, int B, bool signed_p) {
 
 extern "C" size_t iefvad_train_workspace_bytes(const iefvad_handle* h, int32_t B) {
     if (!h || B <= 0 || B > 4096) return 0;
-    return train_layout(h->cfg.num_layers, h->cfg.num_steps, B, train_attn_fused(h)).total * sizeof(float) + 256;
+    return train_layout(h->cfg.num_layers, h->cfg.num_steps, B).total * sizeof(float) + 256;
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------------------------------------------
@@ -305,7 +304,7 @@ static int launch_db(const float* Y, int ld, int ncols, float* db, float* db2, i
 }
 
 // What a train-mode forward leaves on the handle for its backward: which buffer it filled, at which batch size, and whether the
-// dropped copy of the probabilities exists.  A handful of forwards may be outstanding (one record per training buffer).
+// stored probabilities carry a dropout mask.  A handful of forwards may be outstanding (one record per training buffer).
 // Five saved tensors are also outputs (mu and logvar of both modalities, the refined state z_K = `fused`) and two are the inputs: where
 // the caller hands over fp32 buffers of its own, the forward writes / reads THOSE and the backward reads them again (x0, mu, lv, zK
 // below) -- seven device-to-device copies of [rows, 768] per step less (0.33 ms of a 26 ms step).  The caller keeps them untouched
@@ -321,14 +320,13 @@ static void release_train(iefvad_handle* h) {
     h->train = nullptr;
 }
 
-static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t ws_bytes, const char* who, int fused = -1) {
+static int train_check(const iefvad_handle* h, int32_t B, const void* ws, size_t ws_bytes, const char* who) {
     if (!h) return fail("%s: null handle", who);
     if (!h->weights_set) return fail("%s: weights not set", who);
     if (h->cfg.compute != IEFVAD_COMPUTE_F32 && h->cfg.compute != IEFVAD_COMPUTE_BF16X6)
         return fail("%s: training runs in the fp32-accurate arithmetics only (compute f32 or bf16x6)", who);
     if (B <= 0 || B > 4096) return fail("%s: B = %d outside 1..4096", who, B);
-    const size_t need = fused < 0 ? iefvad_train_workspace_bytes(h, B)
-                                  : train_layout(h->cfg.num_layers, h->cfg.num_steps, B, fused != 0).total * sizeof(float) + 256;
+    const size_t need = iefvad_train_workspace_bytes(h, B);
     if (!ws || ws_bytes < need) return fail("%s: training buffer too small (%zu < %zu bytes)", who, ws_bytes, need);
     if ((uintptr_t)ws & 255) return fail("%s: the training buffer must be 256-byte aligned", who);
     return 0;
@@ -379,7 +377,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
                                     void* stream_) {
     if (!h) return fail("iefvad_train_forward: null handle");
     const bool fused = train_attn_fused(h);
-    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_forward", fused)) return rc;
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_forward")) return rc;
     if (!img || !ev || !out || !opt) return fail("iefvad_train_forward: null argument");
     if (in_dtype != IEFVAD_IN_F32 && in_dtype != IEFVAD_IN_F16 && in_dtype != IEFVAD_IN_BF16)
         return fail("iefvad_train_forward: unknown in_dtype %d", in_dtype);
@@ -393,7 +391,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             if (!(opt->dropout_p[m][l] >= 0.f && opt->dropout_p[m][l] < 1.f))
                 return fail("iefvad_train_forward: dropout_p[%d][%d] = %g outside [0, 1)", m, l, (double)opt->dropout_p[m][l]);
     hipStream_t stream = (hipStream_t)stream_;
-    const TrainLayout t = train_layout(L, K, B, fused);
+    const TrainLayout t = train_layout(L, K, B);
     float* ws = (float*)train_ws;
     const int rows = B * IEF_T;
     Timer tm;
@@ -492,7 +490,7 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             if (int rc = launch_bgemm(a, true, true, B * IEF_H, stream)) return rc;
             SoftmaxDropArgs sa;
             sa.S = ws + t.P[m][l];
-            sa.Pd = drop ? ws + t.Pd[m][l] : nullptr;
+            sa.drop = drop ? 1 : 0;
             sa.keep = opt->keep_mask ? opt->keep_mask + ((size_t)m * L + l) * t.PU : nullptr;
             sa.seed = opt->seed * 0x100000001B3ull + (unsigned long long)(m * IEFVAD_MAX_LAYERS + l + 1) * 0x9E3779B97F4A7C15ull;
             sa.p = pdrop;
@@ -501,7 +499,8 @@ extern "C" int iefvad_train_forward(iefvad_handle* h, const void* img, const voi
             HIP_TRY(hipGetLastError());
             // attention output = dropout(P) v
             memset(&a, 0, sizeof(a));
-            a.A = drop ? ws + t.Pd[m][l] : ws + t.P[m][l]; a.B = qkv + 2 * IEF_D; a.C = ws + t.att[m][l];
+            a.A = ws + t.P[m][l]; a.B = qkv + 2 * IEF_D; a.C = ws + t.att[m][l];
+            if (drop) a.a_drop = (float)(1.0 / (1.0 - (double)pdrop));      // dropout(P) from the sign-carrying tensor, in the A tile's staging
             a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = 3 * IEF_D; a.ldc = IEF_D;
             a.a1 = (long long)IEF_H * IEF_T * IEF_T; a.a2 = (long long)IEF_T * IEF_T;
             a.b1 = (long long)IEF_T * 3 * IEF_D; a.b2 = IEF_DH; a.c1 = (long long)IEF_T * IEF_D; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
@@ -585,11 +584,11 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
         for (int i = 0; i < 8; ++i)
             if (h->train->rec[i].ws == train_ws && h->train->rec[i].stamp) rec = &h->train->rec[i];
     if (!rec || rec->B != B) return fail("iefvad_train_backward: no iefvad_train_forward with B = %d has filled this training buffer", B);
-    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_backward", rec->fused)) return rc;
+    if (int rc = train_check(h, B, train_ws, train_ws_bytes, "iefvad_train_backward")) return rc;
     const iefvad_config& c = h->cfg;
     const int L = c.num_layers, K = c.num_steps;
     hipStream_t stream = (hipStream_t)stream_;
-    const TrainLayout t = train_layout(L, K, B, rec->fused);
+    const TrainLayout t = train_layout(L, K, B);
     float* ws = (float*)train_ws;
     const int rows = B * IEF_T;
     const int nblk = (rows + BWD_ROWS_PER_BLOCK - 1) / BWD_ROWS_PER_BLOCK;
@@ -677,11 +676,10 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             float* dP = ws + t.dP;
             const float* qkv = ws + t.qkv[m][l];
             const float* P = ws + t.P[m][l];
-            // Pd is P when neither a dropout probability nor a mask was in force in the forward; after a fused forward P carries the mask
-            // in its sign bits and Pd is formed from it where it is read (the d S launch, the A operand of d v)
-            const float* Pd = rec->drop[m][l] ? ws + t.Pd[m][l] : P;
-            const bool signed_p = rec->fused && rec->drop[m][l];
-            const float drop_scale = (float)(1.0 / (1.0 - (double)rec->drop_p[m][l]));
+            // P carries the dropout mask in its sign bits (when a probability or a mask was in force in the forward): dropout(P) is formed
+            // from it where it is read (the d S launch / the softmax backward, the A operand of d v)
+            const bool signed_p = rec->drop[m][l];
+            const float drop_scale = signed_p ? (float)(1.0 / (1.0 - (double)rec->drop_p[m][l])) : 1.0f;
             { bool db_done = false;
             if (int rc = launch_dw(gx, IEF_D, IEF_D, ws + t.att[m][l], dw->out_proj_w[m][l], nullptr, 0, 1.f, rows, part, t.part_floats, stream, tn, dw->out_proj_b[m][l], nullptr, cpart, t.cpart_floats, &db_done)) return rc;
             if (!db_done)
@@ -715,7 +713,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             }
             // d v = Pd^T d att
             memset(&a, 0, sizeof(a));
-            a.A = Pd; a.B = datt; a.C = dqkv + 2 * IEF_D;
+            a.A = P; a.B = datt; a.C = dqkv + 2 * IEF_D;
             a.M = IEF_T; a.N = IEF_DH; a.K = IEF_T; a.lda = IEF_T; a.ldb = IEF_D; a.ldc = 3 * IEF_D;
             a.a1 = sP1; a.a2 = sP2; a.b1 = sA; a.b2 = IEF_DH; a.c1 = sQ; a.c2 = IEF_DH; a.nz2 = IEF_H; a.alpha = 1.f;
             if (signed_p) a.a_drop = drop_scale;
@@ -723,7 +721,7 @@ extern "C" int iefvad_train_backward(iefvad_handle* h, int32_t B, void* train_ws
             // d S = Pd .* d Pd - P rowsum(Pd .* d Pd)
             if (!ds_fused) {
                 const long long srows = (long long)B * IEF_H * IEF_T;
-                hipLaunchKernelGGL(iefvad_softmax_bwd_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, stream, P, Pd, dP, srows);
+                hipLaunchKernelGGL(iefvad_softmax_bwd_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, stream, P, drop_scale, dP, srows);
                 HIP_TRY(hipGetLastError());
             }
             // d q (before the 1/sqrt(96) scale) = qscale * d S k  (ds_fused: done by the same launch, on the d S in its registers)
