@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void iefvad_gemm_bf16_v1_kernel(GemmBArgs a
 #ifndef GB2_NT_STORES
 #define GB2_NT_STORES 1      // bf16 ring kernel +3..6 % with fp32 results, split kernels +0..1 % (profiles/r02_gemm_nt_stores.log)
 #endif
+#ifndef GB2_NT_RESID
+#define GB2_NT_RESID 0       // experiment (round 5): the epilogue's residual / gate rows as non-temporal loads: +4 % in the stand-alone
+                             // harness (a 200 MB residual buffer re-read every iteration), nothing in the forward (TRIED.md)
+#endif
 #if GB2_NT_STORES
 #define GB2_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
@@ -336,7 +340,9 @@ __device__ __forceinline__ void gemm_wave_epilogue(const GemmBArgs& args, const 
         f32x4 res[16];
         if (has_resid) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) res[u] = *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
+            for (int u = 0; u < 16; ++u)
+                res[u] = GB2_NT_RESID ? __builtin_nontemporal_load((const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol))
+                                      : *(const f32x4*)(P.R + (size_t)(mrow + 2 * u) * ldc + ncol);
         }
         if constexpr (MF16) {
             // 16x16 accumulator map: col = lane & 15, row = 4 (lane >> 4) + reg; this pass takes row sub-tiles 2a, 2a+1
