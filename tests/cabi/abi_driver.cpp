@@ -199,7 +199,45 @@ int main(int argc, char** argv) {
         (void)hipFree(dadj); (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dout); (void)hipFree(gws);
     }
 
-    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK, auc_ap / distance_adj / gcn_forward OK\n", B, L, K, st.total_ms, st.gemm_launches);
+    // the training step's two helpers from plain C++: the loops' NaN rule (ucf_train.py:50-53) and the many-matrix split (a matrix and
+    // its transpose in one launch: plane 0 of the transposed split at (c, r) is plane 0 of the plain split at (r, c))
+    {
+        const int Rn = 128, Cn = 64;
+        const size_t n = (size_t)Rn * Cn;
+        std::vector<float> ha(n), hb(n);
+        for (size_t j = 0; j < n; ++j) { ha[j] = (float)((j * 2654435761u >> 18) & 4095) / 512.f - 4.f; hb[j] = ha[j] * 0.25f; }
+        ha[17] = NAN; ha[99] = INFINITY; hb[5] = -INFINITY;      // a: NaN -> repaired (its infinity too); b: no NaN -> every bit kept
+        float *da = nullptr, *db = nullptr;
+        unsigned* dflags = nullptr;
+        uint16_t *dp = nullptr, *dpt = nullptr;
+        HIPCK(hipMalloc((void**)&da, n * 4)); HIPCK(hipMalloc((void**)&db, n * 4)); HIPCK(hipMalloc((void**)&dflags, 8));
+        HIPCK(hipMalloc((void**)&dp, 3 * n * 2)); HIPCK(hipMalloc((void**)&dpt, 3 * n * 2));
+        HIPCK(hipMemcpy(da, ha.data(), n * 4, hipMemcpyHostToDevice)); HIPCK(hipMemcpy(db, hb.data(), n * 4, hipMemcpyHostToDevice));
+        ABICK(iefvad_nan_rule(da, db, n, dflags, stream));
+        const float* srcs[2] = {db, db};
+        void* dsts[2] = {dp, dpt};
+        const size_t ns[2] = {n, n};
+        const int32_t rows[2] = {0, Rn};
+        ABICK(iefvad_split_bf16x3_many(srcs, dsts, ns, rows, 2, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        unsigned hflags[2];
+        std::vector<float> ra(n), rb(n);
+        std::vector<uint16_t> hp(3 * n), hpt(3 * n);
+        HIPCK(hipMemcpy(hflags, dflags, 8, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(ra.data(), da, n * 4, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(rb.data(), db, n * 4, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(hp.data(), dp, 3 * n * 2, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(hpt.data(), dpt, 3 * n * 2, hipMemcpyDeviceToHost));
+        if (hflags[0] != 1 || hflags[1] != 0 || ra[17] != 0.f || ra[99] != 3.402823466e+38f || memcmp(rb.data(), hb.data(), n * 4) != 0 || ra[18] != ha[18]) {
+            fprintf(stderr, "iefvad_nan_rule: flags %u %u, a[17] %g a[99] %g\n", hflags[0], hflags[1], ra[17], ra[99]);
+            return 9;
+        }
+        for (int p = 0; p < 3; ++p)
+            for (int r = 0; r < Rn; r += 7)
+                for (int c = 0; c < Cn; c += 5)
+                    if (hp[p * n + (size_t)r * Cn + c] != hpt[p * n + (size_t)c * Rn + r]) { fprintf(stderr, "iefvad_split_bf16x3_many: plane %d (%d, %d)\n", p, r, c); return 9; }
+        (void)hipFree(da); (void)hipFree(db); (void)hipFree(dflags); (void)hipFree(dp); (void)hipFree(dpt);
+    }
+
+    printf("abi_driver OK: B=%d L=%d K=%d total %.3f ms, %d GEMM launches, forward_videos OK, gather through librccl OK, auc_ap / distance_adj / gcn_forward / nan_rule / split_many OK\n", B, L, K, st.total_ms, st.gemm_launches);
     iefvad_destroy(h);
     (void)hipFree(ws); (void)hipFree(logits); (void)hipFree(dev); (void)hipStreamDestroy(stream);
     return 0;
