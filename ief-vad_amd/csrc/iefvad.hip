@@ -1890,6 +1890,7 @@ extern "C" int iefvad_loss_forward(const float* logits, const float* image_mu, c
         return fail("Unsupported noise_model. Choose 'Gaussian' or 'StudentT'.");
     if (noise_model == IEFVAD_NOISE_STUDENT_T && !(nu > 0.f)) return fail("iefvad_loss_forward: nu must be positive for StudentT");
     if (workspace_bytes < iefvad_loss_workspace_bytes(B, T)) return fail("iefvad_loss_forward: workspace too small");
+    if ((uintptr_t)workspace & 15) return fail("iefvad_loss_forward: the workspace must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     const int rows = heads ? B * T : 0;
     float* part = (float*)workspace;

@@ -217,6 +217,7 @@ int iefvad_forward_videos_host(iefvad_handle* h, const void* const* img_rows, co
  *   out[7] total = classification + lambda_reg * reg + lambda_kl * kl   (1, 1 in ucf_train.py:100-102; 0.01, 0.01 in xd_train.py:73-75)
  * logits [B, T]; the four 768-d tensors [B*T, 768]; lengths int32 [B] and targets fp32 [B] (1 = abnormal, i.e.
  * 1 - labels[:, 0], loss.py:20) on the DEVICE; out: 8 fp32 on the device.  T must be 256.  Deterministic (no atomics).
+ * `workspace`: iefvad_loss_workspace_bytes(B, T) device bytes, 16-byte aligned.
  * The four 768-d pointers may all be NULL: then only out[0] (and out[7] = out[0]) is computed -- CLAS2 alone.
  * iefvad_loss_backward: the gradients of grad_scale * total with respect to logits [B, T] and the four 768-d tensors (what
  * `loss.backward()` hands to the model's outputs in /root/reference/train/ucf_train.py:103): CLAS2 through torch's BCE
