@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IEFVAD_LIB") or os.path.join(_HERE, "libiefvad.so")      # IEFVAD_LIB: A/B builds of the same ABI (tools)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LAYERS = 8
 MAX_STEPS = 64
 NOISE_GAUSSIAN, NOISE_STUDENT_T = 0, 1
